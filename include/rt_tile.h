@@ -1,0 +1,196 @@
+/*
+ * rt_tile.h — C-ABI of the MI355X path-trace tile renderer.
+ *
+ * Drop-in boundary for ONE hot path of actuday6418/ray-tracer-s8: the body of the
+ * slave's `worker()` NewJob arm (reference ray-tracer-slave/src/main.rs:37-83) and
+ * everything it calls (`ray_color` main.rs:108-146, `Camera::get_ray` camera.rs:109-129,
+ * `WorldRefList::intersect` shapes/mod.rs:158-191, Sphere/Triangle `get_roots`).
+ *
+ * The reference has no FFI; its seam is the controller->slave JSON `RenderInfo`
+ * (ray-tracer-slave/src/lib.rs:10-15) answered by `ImageSlice` (lib.rs:17-22).  This
+ * header carries exactly those fields as POD, plus the knobs the reference hard-codes
+ * (main.rs:39,42-51; shapes/mod.rs:12-13) with the reference literals as defaults.
+ *
+ * Plain C: POD structs, pointers and sizes only.  A Rust `extern "C"` block, cgo or
+ * ctypes can bind it verbatim.
+ *
+ * Every function returns an `rt_status` (0 = OK, negative = error) and never throws
+ * or aborts across the boundary (the reference panics via `.unwrap()`).  Caller owns
+ * every pointer before and after each call; the library copies in and retains nothing
+ * outside an explicit `rt_scene` handle.
+ */
+#ifndef RT_TILE_H
+#define RT_TILE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(_WIN32)
+#define RT_API
+#else
+#define RT_API __attribute__((visibility("default")))
+#endif
+
+#define RT_ABI_VERSION 1u
+
+/* ---- status codes --------------------------------------------------------------- */
+typedef enum rt_status {
+    RT_OK = 0,
+    RT_ERR_BAD_ARG = -1,        /* null pointer, zero size, division_no >= divisions ...      */
+    RT_ERR_NOT_INITIALIZED = -2,/* rt_init() not called / failed                              */
+    RT_ERR_NO_DEVICE = -3,      /* no MI355X-class HIP device visible (no CPU fallback)       */
+    RT_ERR_BAD_DEVICE = -4,     /* device ordinal out of range                                */
+    RT_ERR_BUFFER_TOO_SMALL = -5,/* out_len < (H/div)*W*3                                     */
+    RT_ERR_FRAME_SIZE = -6,     /* frame assembly asked with height % divisions != 0
+                                   (reference controller panics: controller/src/main.rs:117-119) */
+    RT_ERR_HIP = -7,            /* a HIP runtime call failed; see rt_last_error()             */
+    RT_ERR_LIMIT = -8,          /* max_bounces > RT_MAX_BOUNCES, n_spheres too large ...      */
+    RT_ERR_OOM = -9             /* host or device allocation failed                           */
+} rt_status;
+
+#define RT_MAX_BOUNCES 62u      /* path stack depth limit (reference literal is 10)           */
+
+/* ---- scene primitives ----------------------------------------------------------- */
+
+/* = reference `Sphere` (ray-tracer-slave/src/shapes/sphere.rs:12-20) minus `node_index`
+ * (a BVH back-pointer the linear GPU scan does not use).  36 bytes, no padding. */
+typedef struct rt_sphere {
+    float cx, cy, cz;           /* center                                                     */
+    float radius;
+    float albedo_r, albedo_g, albedo_b; /* p_albedo_at                                        */
+    float roughness;            /* p_roughness_at: 0 = Lambertian, 1 = mirror (main.rs:122)   */
+    float emission;             /* p_emission_at: > 0 terminates the path (main.rs:116-117)   */
+} rt_sphere;
+
+/* = reference `Triangle` (ray-tracer-slave/src/shapes/mesh.rs:14-23) minus `node_index`.
+ * 56 bytes, no padding. */
+typedef struct rt_triangle {
+    float a[3], b[3], c[3];
+    float albedo_r, albedo_g, albedo_b;
+    float roughness;
+    float emission;
+} rt_triangle;
+
+/* ---- tile request = RenderMeta + division_no + the hard-coded knobs ------------- */
+
+enum {
+    RT_FLAG_NONE = 0u,
+    /* Disable the conservative broad-phase filter: run the reference's exact root
+     * computation against every primitive (slow; used by tests to prove the filter
+     * never changes a result). */
+    RT_FLAG_EXACT_SCAN = 1u << 0
+};
+
+typedef struct rt_tile_request {
+    /* RenderMeta (lib.rs:24-30); `id` (UUID) is opaque to the renderer, stays with caller */
+    uint32_t width;             /* image width  W                                             */
+    uint32_t height;            /* image height H                                             */
+    uint32_t divisions;         /* number of horizontal strips; strip height Hs = H / div     */
+    /* RenderInfo.division_no (lib.rs:14): strip index, 0 = TOP of the image (main.rs:66-71)  */
+    uint32_t division_no;
+    /* knobs the reference hard-codes; rt_tile_request_defaults() fills the literals         */
+    uint32_t spp;               /* sample_count   = 100   (main.rs:51)                        */
+    uint32_t max_bounces;       /* max_bounces    = 10    (main.rs:39); ray_color depth = +1  */
+    float aperture;             /* 0.1            (main.rs:45)                                */
+    float focus_distance;       /* 1.0            (main.rs:46)                                */
+    float fov;                  /* PI/2 (f32)     (main.rs:47)                                */
+    float focal_length;         /* 1.0            (main.rs:48)                                */
+    float t_min;                /* 0.001          (shapes/mod.rs:12)                          */
+    float t_max;                /* 1000.0         (shapes/mod.rs:13), half-open [t_min,t_max) */
+    /* new: replaces `SmallRng::from_entropy()` per row (main.rs:69) by a deterministic
+     * per-pixel xoshiro256++ stream; see DESIGN.md "RNG". */
+    uint64_t seed;
+    uint32_t flags;             /* RT_FLAG_*                                                  */
+    uint32_t reserved;          /* must be 0                                                  */
+} rt_tile_request;
+
+typedef struct rt_tile_stats {
+    uint64_t ray_segments;      /* ray_color entries with depth > 0 (closest-hit queries)     */
+    uint64_t primary_rays;      /* Hs * W * spp                                               */
+    uint64_t broad_candidates;  /* primitives that passed the broad phase (0 in exact scan)   */
+    uint64_t exact_fallbacks;   /* segments whose candidate list overflowed (exact rescans)   */
+    float kernel_ms;            /* HIP-event time of the kernel(s) of this call               */
+    float h2d_ms;               /* scene upload (0 when a resident rt_scene is used)          */
+    float d2h_ms;               /* RGB8 strip download (0 for device output)                  */
+    uint32_t n_launches;        /* kernel launches issued by this call                        */
+} rt_tile_stats;
+
+/* ---- lifecycle ------------------------------------------------------------------ */
+
+/* Enumerate HIP devices, create one context (stream + events + counters) per device.
+ * *n_devices may be NULL.  Returns RT_ERR_NO_DEVICE if none: there is NO CPU fallback. */
+RT_API int rt_init(int* n_devices);
+RT_API void rt_shutdown(void);
+RT_API uint32_t rt_abi_version(void);
+RT_API const char* rt_strerror(int status);
+/* Last error message of the calling thread ("" if none). */
+RT_API const char* rt_last_error(void);
+
+/* Fill the reference literals (main.rs:39-51, shapes/mod.rs:12-13, controller main.rs:33-39:
+ * 1920x1080, 20 divisions); seed 0, flags 0. */
+RT_API void rt_tile_request_defaults(rt_tile_request* req);
+
+/* Bytes of one strip = (H / div) * W * 3  (main.rs:53-59).  0 on bad args. */
+RT_API size_t rt_tile_bytes(const rt_tile_request* req);
+
+/* ---- one strip, host buffers: replaces slave main.rs:53-83 ---------------------- */
+
+/* Render strip `req->division_no` of the frame on `device` into out_rgb
+ * (= ImageSlice.image: Hs*W*3 bytes, RGB8, row-major, top row of the strip first).
+ * Synchronous.  Thread-safe across devices; calls on one device serialise.
+ * Empty world (n_spheres + n_triangles == 0) renders the sky (the reference recurses
+ * without bound in BVH::build, bvh_impl.rs:229-364).
+ * Like the slave, accepts height % divisions != 0 and renders floor(H/div) rows.
+ * out_f32 (optional, may be NULL): Hs*W*3 floats, post-gamma pre-quantise pixel values. */
+RT_API int rt_render_tile(int device, const rt_tile_request* req,
+                          const rt_sphere* spheres, uint32_t n_spheres,
+                          const rt_triangle* triangles, uint32_t n_triangles,
+                          uint8_t* out_rgb, size_t out_len,
+                          float* out_f32, rt_tile_stats* stats);
+
+/* ---- resident scene: upload the world once per device per job ------------------- */
+/* (the reference re-sends and re-builds per strip: controller main.rs:58-62, slave main.rs:60) */
+
+typedef struct rt_scene rt_scene;
+
+RT_API int rt_scene_create(int device,
+                           const rt_sphere* spheres, uint32_t n_spheres,
+                           const rt_triangle* triangles, uint32_t n_triangles,
+                           rt_scene** out_scene);
+RT_API void rt_scene_destroy(rt_scene* scene);
+
+/* Same as rt_render_tile, scene already in HBM. */
+RT_API int rt_scene_render_tile(rt_scene* scene, const rt_tile_request* req,
+                                uint8_t* out_rgb, size_t out_len,
+                                float* out_f32, rt_tile_stats* stats);
+
+/* Asynchronous, device-resident output: enqueue the strip on `hip_stream`
+ * (a hipStream_t; NULL = the scene's own stream) writing RGB8 to device memory
+ * d_out_rgb (>= rt_tile_bytes) and, if non-NULL, floats to d_out_f32.
+ * Counters and HIP-event timings accumulate in the scene until rt_scene_collect(). */
+RT_API int rt_scene_render_tile_device(rt_scene* scene, const rt_tile_request* req,
+                                       void* d_out_rgb, size_t out_len,
+                                       void* d_out_f32, void* hip_stream);
+
+/* Wait for all work enqueued on the scene, return accumulated counters / event time
+ * since the previous collect, and reset them. */
+RT_API int rt_scene_collect(rt_scene* scene, rt_tile_stats* stats);
+
+/* ---- whole frame: replaces controller dispatch + assembly ----------------------- */
+/* (controller main.rs:47-75 `for division_no in 0..divisions` and :109-115 stitch).
+ * Strip k goes to devices[k % n_devices] (one host thread + stream per device), the
+ * RGB8 strips are stitched by division_no into out_rgb (H*W*3).  devices==NULL means
+ * all devices.  req->division_no is ignored.  height % divisions must be 0. */
+RT_API int rt_render_frame(const int* devices, int n_devices, const rt_tile_request* req,
+                           const rt_sphere* spheres, uint32_t n_spheres,
+                           const rt_triangle* triangles, uint32_t n_triangles,
+                           uint8_t* out_rgb, size_t out_len, rt_tile_stats* stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_TILE_H */

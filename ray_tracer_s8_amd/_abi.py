@@ -1,0 +1,162 @@
+"""ctypes binding of include/rt_tile.h — the same stub a cgo / Rust `extern "C"` user
+would write.  Loading fails loudly when the HIP library is missing:
+there is no CPU fallback in the product path."""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+from . import build as _build
+
+# ---- status codes (rt_status)
+RT_OK = 0
+RT_ERR_BAD_ARG = -1
+RT_ERR_NOT_INITIALIZED = -2
+RT_ERR_NO_DEVICE = -3
+RT_ERR_BAD_DEVICE = -4
+RT_ERR_BUFFER_TOO_SMALL = -5
+RT_ERR_FRAME_SIZE = -6
+RT_ERR_HIP = -7
+RT_ERR_LIMIT = -8
+RT_ERR_OOM = -9
+
+RT_FLAG_NONE = 0
+RT_FLAG_EXACT_SCAN = 1
+RT_MAX_BOUNCES = 62
+
+# numpy dtypes with the exact layout of rt_sphere / rt_triangle (no padding)
+SPHERE_DTYPE = np.dtype(
+    [("cx", "<f4"), ("cy", "<f4"), ("cz", "<f4"), ("radius", "<f4"),
+     ("albedo_r", "<f4"), ("albedo_g", "<f4"), ("albedo_b", "<f4"),
+     ("roughness", "<f4"), ("emission", "<f4")]
+)
+TRIANGLE_DTYPE = np.dtype(
+    [("a", "<f4", 3), ("b", "<f4", 3), ("c", "<f4", 3),
+     ("albedo_r", "<f4"), ("albedo_g", "<f4"), ("albedo_b", "<f4"),
+     ("roughness", "<f4"), ("emission", "<f4")]
+)
+assert SPHERE_DTYPE.itemsize == 36 and TRIANGLE_DTYPE.itemsize == 56
+
+
+class TileRequest(C.Structure):
+    """rt_tile_request = RenderMeta + division_no + the knobs the reference hard-codes."""
+    _fields_ = [
+        ("width", C.c_uint32), ("height", C.c_uint32), ("divisions", C.c_uint32),
+        ("division_no", C.c_uint32), ("spp", C.c_uint32), ("max_bounces", C.c_uint32),
+        ("aperture", C.c_float), ("focus_distance", C.c_float), ("fov", C.c_float),
+        ("focal_length", C.c_float), ("t_min", C.c_float), ("t_max", C.c_float),
+        ("seed", C.c_uint64), ("flags", C.c_uint32), ("reserved", C.c_uint32),
+    ]
+
+    def copy(self) -> "TileRequest":
+        r = TileRequest()
+        C.memmove(C.byref(r), C.byref(self), C.sizeof(TileRequest))
+        return r
+
+
+class TileStats(C.Structure):
+    _fields_ = [
+        ("ray_segments", C.c_uint64), ("primary_rays", C.c_uint64),
+        ("broad_candidates", C.c_uint64), ("exact_fallbacks", C.c_uint64),
+        ("kernel_ms", C.c_float), ("h2d_ms", C.c_float), ("d2h_ms", C.c_float),
+        ("n_launches", C.c_uint32),
+    ]
+
+
+assert C.sizeof(TileRequest) == 64
+
+
+def default_request(**kw) -> TileRequest:
+    """Reference literals (slave main.rs:39-51, shapes/mod.rs:12-13, controller main.rs:33-39).
+    Pure Python so that host-side code and CPU tests need no GPU library."""
+    r = TileRequest(width=1920, height=1080, divisions=20, division_no=0, spp=100, max_bounces=10,
+                    aperture=0.1, focus_distance=1.0, fov=float(np.float32(np.pi) / np.float32(2.0)),
+                    focal_length=1.0, t_min=0.001, t_max=1000.0, seed=0, flags=0, reserved=0)
+    for k, v in kw.items():
+        if not hasattr(r, k):
+            raise AttributeError(k)
+        setattr(r, k, v)
+    return r
+
+
+class RtError(RuntimeError):
+    def __init__(self, status: int, what: str, detail: str):
+        super().__init__(f"{what}: status {status} ({detail})")
+        self.status = status
+
+
+_lib = None
+
+
+def lib_path() -> Path:
+    return _build.LIB_PATH
+
+
+def load(build_if_missing: bool = True) -> C.CDLL:
+    """Load librt_s8.so (building it with hipcc if absent).  Raises if it cannot."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB_PATH
+    if build_if_missing:
+        path = _build.build()
+    if not path.exists():
+        raise FileNotFoundError(
+            f"{path} not found: the HIP extension is required (run `python -m ray_tracer_s8_amd.build`); "
+            "there is no CPU fallback")
+    lib = C.CDLL(str(path))
+    u8p, f32p, vp = C.POINTER(C.c_uint8), C.POINTER(C.c_float), C.c_void_p
+    lib.rt_init.argtypes = [C.POINTER(C.c_int)]
+    lib.rt_init.restype = C.c_int
+    lib.rt_shutdown.argtypes = []
+    lib.rt_shutdown.restype = None
+    lib.rt_abi_version.argtypes = []
+    lib.rt_abi_version.restype = C.c_uint32
+    lib.rt_strerror.argtypes = [C.c_int]
+    lib.rt_strerror.restype = C.c_char_p
+    lib.rt_last_error.argtypes = []
+    lib.rt_last_error.restype = C.c_char_p
+    lib.rt_tile_request_defaults.argtypes = [C.POINTER(TileRequest)]
+    lib.rt_tile_request_defaults.restype = None
+    lib.rt_tile_bytes.argtypes = [C.POINTER(TileRequest)]
+    lib.rt_tile_bytes.restype = C.c_size_t
+    lib.rt_render_tile.argtypes = [C.c_int, C.POINTER(TileRequest), vp, C.c_uint32, vp, C.c_uint32,
+                                   vp, C.c_size_t, vp, C.POINTER(TileStats)]
+    lib.rt_render_tile.restype = C.c_int
+    lib.rt_scene_create.argtypes = [C.c_int, vp, C.c_uint32, vp, C.c_uint32, C.POINTER(vp)]
+    lib.rt_scene_create.restype = C.c_int
+    lib.rt_scene_destroy.argtypes = [vp]
+    lib.rt_scene_destroy.restype = None
+    lib.rt_scene_render_tile.argtypes = [vp, C.POINTER(TileRequest), vp, C.c_size_t, vp, C.POINTER(TileStats)]
+    lib.rt_scene_render_tile.restype = C.c_int
+    lib.rt_scene_render_tile_device.argtypes = [vp, C.POINTER(TileRequest), vp, C.c_size_t, vp, vp]
+    lib.rt_scene_render_tile_device.restype = C.c_int
+    lib.rt_scene_collect.argtypes = [vp, C.POINTER(TileStats)]
+    lib.rt_scene_collect.restype = C.c_int
+    lib.rt_render_frame.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(TileRequest), vp, C.c_uint32,
+                                    vp, C.c_uint32, vp, C.c_size_t, C.POINTER(TileStats)]
+    lib.rt_render_frame.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str) -> None:
+    if status != RT_OK:
+        lib = load()
+        raise RtError(status, what, f"{lib.rt_strerror(status).decode()}: {lib.rt_last_error().decode()}")
+
+
+def as_spheres(a) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=SPHERE_DTYPE) if a is not None else np.zeros(0, SPHERE_DTYPE)
+    return a
+
+
+def as_triangles(a) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=TRIANGLE_DTYPE) if a is not None else np.zeros(0, TRIANGLE_DTYPE)
+    return a
+
+
+def ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p) if a.size else None

@@ -1,0 +1,569 @@
+// rt_api.hip — host side of the C-ABI declared in include/rt_tile.h.
+//
+// Plays the roles the reference gives to the slave's worker (ray-tracer-slave/src/main.rs:32-106:
+// take a RenderInfo, produce the strip's RGB8 bytes) and, in rt_render_frame, to the
+// controller's dispatch + assembly (ray-tracer-controller/src/main.rs:47-75, 109-115).
+// No torch types, no CPU fallback: without a HIP device every entry point fails loudly.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "rt_kernel.hip.h"
+#include "rt_tile.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                                  \
+    do {                                                                                              \
+        hipError_t _e = (expr);                                                                       \
+        if (_e != hipSuccess)                                                                         \
+            return fail(RT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e) + " (" __FILE__ \
+                                                                                        ":" +         \
+                                        std::to_string(__LINE__) + ")");                              \
+    } while (0)
+
+struct DeviceCtx {
+    int dev = -1;
+    hipStream_t stream = nullptr;
+    std::mutex mu;   // serialises synchronous calls on one device
+};
+
+std::mutex g_mu;
+bool g_init = false;
+std::vector<DeviceCtx*> g_ctx;
+
+constexpr size_t LDS_LIMIT = 160 * 1024 - 1024;   // dynamic LDS budget; 1 KiB left for the kernels' static LDS
+constexpr uint32_t RESIDENT_MAX = rtk::CHUNK;   // spheres kept wholly in LDS
+constexpr uint32_t STREAM_CHUNK = 2048;         // chunk size when streaming through LDS
+
+}  // namespace
+
+struct rt_scene {
+    DeviceCtx* ctx = nullptr;
+    uint32_t n_sph = 0, n_sph_pad = 0, n_tri = 0;
+    float4* d_geom = nullptr;
+    float4* d_mat = nullptr;
+    float* d_emis = nullptr;
+    float* d_tri = nullptr;
+    unsigned long long* d_counters = nullptr;
+    // staging for the host-buffer entry point (grown on demand)
+    uint8_t* d_out = nullptr;
+    size_t d_out_cap = 0;
+    float* d_outf = nullptr;
+    size_t d_outf_cap = 0;
+    // HIP-event bookkeeping of launches not yet collected
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending, free_ev;
+    uint64_t primary_rays = 0;
+    float h2d_ms = 0.f;
+    std::mutex mu;
+};
+
+namespace {
+
+int check_request(const rt_tile_request* rq) {
+    if (!rq) return fail(RT_ERR_BAD_ARG, "request is NULL");
+    if (rq->width == 0 || rq->height == 0 || rq->divisions == 0 || rq->spp == 0)
+        return fail(RT_ERR_BAD_ARG, "width, height, divisions and spp must be non-zero");
+    if (rq->division_no >= rq->divisions) return fail(RT_ERR_BAD_ARG, "division_no >= divisions");
+    if (rq->height / rq->divisions == 0) return fail(RT_ERR_BAD_ARG, "height / divisions == 0 rows");
+    if (rq->max_bounces > RT_MAX_BOUNCES) return fail(RT_ERR_LIMIT, "max_bounces > RT_MAX_BOUNCES");
+    if (rq->reserved != 0) return fail(RT_ERR_BAD_ARG, "reserved must be 0");
+    if ((uint64_t)rq->width * rq->height > 0x7fffffffull) return fail(RT_ERR_LIMIT, "image too large");
+    return RT_OK;
+}
+
+// Camera::new with the slave's arguments (main.rs:42-50 -> camera.rs:19-47)
+void fill_camera(const rt_tile_request* rq, rtk::KParams& p) {
+    const float origin[3] = {0.f, 0.f, 0.f};          // Point3::ZERO
+    const float aspect_ratio = (float)rq->width / (float)rq->height;
+    const float image_height = (float)rq->height;
+    const float vh = 2.0f * std::tan(rq->fov / 2.0f);
+    const float vw = aspect_ratio * vh;
+    const float hor[3] = {vw, 0.f, 0.f}, ver[3] = {0.f, vh, 0.f};
+    const float foc[3] = {0.f, 0.f, rq->focal_length};
+    for (int i = 0; i < 3; i++) {
+        p.org[i] = origin[i];
+        p.hor[i] = hor[i];
+        p.ver[i] = ver[i];
+        // origin - horizontal / 2 - vertical / 2 - (0,0,focal_length)
+        float v = origin[i] - hor[i] / 2.0f;
+        v = v - ver[i] / 2.0f;
+        v = v - foc[i];
+        p.llc[i] = v;
+    }
+    p.lens_radius = rq->aperture / 2.0f;
+    p.focus_distance = rq->focus_distance;
+    p.u_den = aspect_ratio * image_height - 1.0f;      // camera.rs:116
+    p.v_den = image_height - 1.0f;                     // camera.rs:117
+}
+
+struct EvPair {
+    hipEvent_t a, b;
+};
+
+int get_events(rt_scene* sc, EvPair& ev) {
+    if (!sc->free_ev.empty()) {
+        ev.a = sc->free_ev.back().first;
+        ev.b = sc->free_ev.back().second;
+        sc->free_ev.pop_back();
+        return RT_OK;
+    }
+    HIPCHK(hipEventCreate(&ev.a));
+    HIPCHK(hipEventCreate(&ev.b));
+    return RT_OK;
+}
+
+// Enqueue one strip.  Caller holds sc->mu and has the device current.
+int launch_tile(rt_scene* sc, const rt_tile_request* rq, void* d_rgb, void* d_f32, hipStream_t stream) {
+    rtk::KParams p;
+    std::memset(&p, 0, sizeof p);
+    p.W = rq->width;
+    p.H = rq->height;
+    p.Hs = rq->height / rq->divisions;
+    p.y0 = p.Hs * rq->division_no;
+    p.spp = rq->spp;
+    p.depth = rq->max_bounces + 1;
+    p.n_sph = sc->n_sph;
+    p.n_sph_pad = sc->n_sph_pad;
+    p.n_tri = sc->n_tri;
+    p.flags = rq->flags;
+    const bool streamed = sc->n_sph_pad > RESIDENT_MAX;
+    p.chunk = streamed ? STREAM_CHUNK : sc->n_sph_pad;
+    p.n_chunks = p.chunk ? (sc->n_sph_pad + p.chunk - 1) / p.chunk : 0;
+    p.path32 = (sc->n_sph + sc->n_tri) > 65536u ? 1u : 0u;
+    size_t geom_bytes = (size_t)(p.chunk ? p.chunk : 1) * sizeof(float4);
+    p.lds_cand_off = (uint32_t)geom_bytes;
+    size_t cand_bytes = (size_t)rtk::MAXC * rtk::BLOCK * sizeof(uint16_t);
+    p.lds_path_off = (uint32_t)(geom_bytes + cand_bytes);
+    size_t path_bytes = (size_t)p.depth * rtk::BLOCK * (p.path32 ? 4 : 2);
+    size_t lds = geom_bytes + cand_bytes + path_bytes;
+    if (lds > LDS_LIMIT) return fail(RT_ERR_LIMIT, "LDS budget exceeded (scene chunk + path stack)");
+    p.seed = rq->seed;
+    fill_camera(rq, p);
+    p.t_min = rq->t_min;
+    p.t_max = rq->t_max;
+    p.spp_f = (float)rq->spp;
+    p.geom = sc->d_geom;
+    p.mat = sc->d_mat;
+    p.emis = sc->d_emis;
+    p.tri = sc->d_tri;
+    p.out_rgb = (uint8_t*)d_rgb;
+    p.out_f32 = (float*)d_f32;
+    p.counters = sc->d_counters;
+
+    dim3 grid((p.W + rtk::TILE_W - 1) / rtk::TILE_W, (p.Hs + rtk::TILE_H - 1) / rtk::TILE_H);
+    dim3 block(rtk::BLOCK);
+    EvPair ev;
+    int rc = get_events(sc, ev);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(ev.a, stream));
+    if (streamed)
+        hipLaunchKernelGGL(rtk::rt_tile_kernel<true>, grid, block, lds, stream, p);
+    else
+        hipLaunchKernelGGL(rtk::rt_tile_kernel<false>, grid, block, lds, stream, p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(ev.b, stream));
+    sc->pending.push_back({ev.a, ev.b});
+    sc->primary_rays += (uint64_t)p.Hs * p.W * p.spp;
+    return RT_OK;
+}
+
+int collect_locked(rt_scene* sc, rt_tile_stats* st) {
+    float ms = 0.f;
+    uint32_t n = 0;
+    for (auto& pr : sc->pending) {
+        HIPCHK(hipEventSynchronize(pr.second));
+        float t = 0.f;
+        HIPCHK(hipEventElapsedTime(&t, pr.first, pr.second));
+        ms += t;
+        n++;
+        sc->free_ev.push_back(pr);
+    }
+    sc->pending.clear();
+    unsigned long long c[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpy(c, sc->d_counters, sizeof c, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(sc->d_counters, 0, sizeof c));
+    if (st) {
+        st->ray_segments = c[0];
+        st->broad_candidates = c[1];
+        st->exact_fallbacks = c[2];
+        st->primary_rays = sc->primary_rays;
+        st->kernel_ms = ms;
+        st->n_launches = n;
+        st->h2d_ms = sc->h2d_ms;
+        st->d2h_ms = 0.f;
+    }
+    sc->primary_rays = 0;
+    sc->h2d_ms = 0.f;
+    return RT_OK;
+}
+
+}  // namespace
+
+// =====================================================================================
+extern "C" {
+
+RT_API uint32_t rt_abi_version(void) { return RT_ABI_VERSION; }
+
+RT_API const char* rt_strerror(int status) {
+    switch (status) {
+        case RT_OK: return "ok";
+        case RT_ERR_BAD_ARG: return "bad argument";
+        case RT_ERR_NOT_INITIALIZED: return "rt_init() has not succeeded";
+        case RT_ERR_NO_DEVICE: return "no HIP device (this library has no CPU fallback)";
+        case RT_ERR_BAD_DEVICE: return "device ordinal out of range";
+        case RT_ERR_BUFFER_TOO_SMALL: return "output buffer smaller than (height/divisions)*width*3";
+        case RT_ERR_FRAME_SIZE: return "height is not a multiple of divisions";
+        case RT_ERR_HIP: return "HIP runtime error";
+        case RT_ERR_LIMIT: return "limit exceeded";
+        case RT_ERR_OOM: return "out of memory";
+        default: return "unknown status";
+    }
+}
+
+RT_API const char* rt_last_error(void) { return g_err.c_str(); }
+
+RT_API void rt_tile_request_defaults(rt_tile_request* rq) {
+    if (!rq) return;
+    std::memset(rq, 0, sizeof *rq);
+    rq->width = 1920;                 // controller main.rs:33-39
+    rq->height = 1080;
+    rq->divisions = 20;
+    rq->division_no = 0;
+    rq->spp = 100;                    // slave main.rs:51
+    rq->max_bounces = 10;             // main.rs:39
+    rq->aperture = 0.1f;              // main.rs:45
+    rq->focus_distance = 1.0f;        // main.rs:46
+    rq->fov = 3.14159265358979323846f / 2.0f;   // PI / 2f32, main.rs:47
+    rq->focal_length = 1.0f;          // main.rs:48
+    rq->t_min = 0.001f;               // shapes/mod.rs:12
+    rq->t_max = 1000.0f;              // shapes/mod.rs:13
+    rq->seed = 0;
+    rq->flags = RT_FLAG_NONE;
+}
+
+RT_API size_t rt_tile_bytes(const rt_tile_request* rq) {
+    if (!rq || rq->divisions == 0) return 0;
+    return (size_t)(rq->height / rq->divisions) * rq->width * 3;   // main.rs:53-59
+}
+
+RT_API int rt_init(int* n_devices) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_init) {
+        if (n_devices) *n_devices = (int)g_ctx.size();
+        return RT_OK;
+    }
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        if (n_devices) *n_devices = 0;
+        return fail(RT_ERR_NO_DEVICE, std::string("hipGetDeviceCount: ") +
+                                          (e != hipSuccess ? hipGetErrorString(e) : "0 devices"));
+    }
+    for (int d = 0; d < n; d++) {
+        HIPCHK(hipSetDevice(d));
+        DeviceCtx* c = new DeviceCtx;
+        c->dev = d;
+        HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        HIPCHK(hipFuncSetAttribute((const void*)rtk::rt_tile_kernel<false>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
+        HIPCHK(hipFuncSetAttribute((const void*)rtk::rt_tile_kernel<true>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
+        g_ctx.push_back(c);
+    }
+    g_init = true;
+    if (n_devices) *n_devices = n;
+    return RT_OK;
+}
+
+RT_API void rt_shutdown(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (DeviceCtx* c : g_ctx) {
+        (void)hipSetDevice(c->dev);
+        if (c->stream) (void)hipStreamDestroy(c->stream);
+        delete c;
+    }
+    g_ctx.clear();
+    g_init = false;
+}
+
+RT_API int rt_scene_create(int device, const rt_sphere* sp, uint32_t ns, const rt_triangle* tr, uint32_t nt,
+                           rt_scene** out) {
+    if (!out) return fail(RT_ERR_BAD_ARG, "out_scene is NULL");
+    *out = nullptr;
+    if ((ns && !sp) || (nt && !tr)) return fail(RT_ERR_BAD_ARG, "primitive pointer is NULL");
+    if (!g_init) return fail(RT_ERR_NOT_INITIALIZED, "call rt_init() first");
+    if (device < 0 || device >= (int)g_ctx.size()) return fail(RT_ERR_BAD_DEVICE, "bad device ordinal");
+    if ((uint64_t)ns + nt > 0x7ffffff0ull) return fail(RT_ERR_LIMIT, "too many primitives");
+    DeviceCtx* ctx = g_ctx[device];
+    HIPCHK(hipSetDevice(ctx->dev));
+    rt_scene* sc = new (std::nothrow) rt_scene;
+    if (!sc) return fail(RT_ERR_OOM, "host allocation failed");
+    sc->ctx = ctx;
+    sc->n_sph = ns;
+    sc->n_tri = nt;
+    sc->n_sph_pad = (ns + rtk::UNROLL - 1) / rtk::UNROLL * rtk::UNROLL;
+    const uint32_t np = ns + nt;
+    std::vector<float4> geom(sc->n_sph_pad ? sc->n_sph_pad : 1);
+    std::vector<float4> mat(np ? np : 1);
+    std::vector<float> emis(np ? np : 1);
+    std::vector<float> tri((size_t)nt * 9 + 1);
+    for (uint32_t i = 0; i < ns; i++) {
+        // rr = radius.powi(2) (sphere.rs:45): one rounded multiply
+        volatile float rr = sp[i].radius * sp[i].radius;
+        geom[i] = make_float4(sp[i].cx, sp[i].cy, sp[i].cz, rr);
+        mat[i] = make_float4(sp[i].albedo_r, sp[i].albedo_g, sp[i].albedo_b, sp[i].roughness);
+        emis[i] = sp[i].emission;
+    }
+    // padding spheres can never pass either phase: rr = -inf makes every discriminant -inf
+    for (uint32_t i = ns; i < sc->n_sph_pad; i++) geom[i] = make_float4(0.f, 0.f, 0.f, -INFINITY);
+    for (uint32_t i = 0; i < nt; i++) {
+        std::memcpy(&tri[(size_t)i * 9], tr[i].a, 9 * sizeof(float));
+        mat[ns + i] = make_float4(tr[i].albedo_r, tr[i].albedo_g, tr[i].albedo_b, tr[i].roughness);
+        emis[ns + i] = tr[i].emission;
+    }
+    auto cleanup = [&](int code) {
+        rt_scene_destroy(sc);
+        return code;
+    };
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
+        return cleanup(fail(RT_ERR_HIP, "hipEventCreate failed"));
+#define SC_CHK(expr)                                                                      \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess) {                                                           \
+            (void)hipEventDestroy(e0);                                                    \
+            (void)hipEventDestroy(e1);                                                    \
+            return cleanup(fail(_e == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_HIP,      \
+                                std::string(#expr) + ": " + hipGetErrorString(_e)));      \
+        }                                                                                 \
+    } while (0)
+    SC_CHK(hipMalloc(&sc->d_geom, geom.size() * sizeof(float4)));
+    SC_CHK(hipMalloc(&sc->d_mat, mat.size() * sizeof(float4)));
+    SC_CHK(hipMalloc(&sc->d_emis, emis.size() * sizeof(float)));
+    SC_CHK(hipMalloc(&sc->d_tri, tri.size() * sizeof(float)));
+    SC_CHK(hipMalloc(&sc->d_counters, 4 * sizeof(unsigned long long)));
+    SC_CHK(hipEventRecord(e0, ctx->stream));
+    SC_CHK(hipMemcpyAsync(sc->d_geom, geom.data(), geom.size() * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+    SC_CHK(hipMemcpyAsync(sc->d_mat, mat.data(), mat.size() * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+    SC_CHK(hipMemcpyAsync(sc->d_emis, emis.data(), emis.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    SC_CHK(hipMemcpyAsync(sc->d_tri, tri.data(), tri.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    SC_CHK(hipMemsetAsync(sc->d_counters, 0, 4 * sizeof(unsigned long long), ctx->stream));
+    SC_CHK(hipEventRecord(e1, ctx->stream));
+    SC_CHK(hipEventSynchronize(e1));
+    SC_CHK(hipEventElapsedTime(&sc->h2d_ms, e0, e1));
+#undef SC_CHK
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *out = sc;
+    return RT_OK;
+}
+
+RT_API void rt_scene_destroy(rt_scene* sc) {
+    if (!sc) return;
+    if (sc->ctx) (void)hipSetDevice(sc->ctx->dev);
+    for (auto& pr : sc->pending) {
+        (void)hipEventSynchronize(pr.second);
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
+    for (auto& pr : sc->free_ev) {
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
+    (void)hipFree(sc->d_geom);
+    (void)hipFree(sc->d_mat);
+    (void)hipFree(sc->d_emis);
+    (void)hipFree(sc->d_tri);
+    (void)hipFree(sc->d_counters);
+    (void)hipFree(sc->d_out);
+    (void)hipFree(sc->d_outf);
+    delete sc;
+}
+
+RT_API int rt_scene_render_tile_device(rt_scene* sc, const rt_tile_request* rq, void* d_out_rgb, size_t out_len,
+                                       void* d_out_f32, void* hip_stream) {
+    if (!sc) return fail(RT_ERR_BAD_ARG, "scene is NULL");
+    int rc = check_request(rq);
+    if (rc) return rc;
+    if (!d_out_rgb) return fail(RT_ERR_BAD_ARG, "d_out_rgb is NULL");
+    if (out_len < rt_tile_bytes(rq)) return fail(RT_ERR_BUFFER_TOO_SMALL, "out_len < (H/div)*W*3");
+    std::lock_guard<std::mutex> lk(sc->mu);
+    HIPCHK(hipSetDevice(sc->ctx->dev));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : sc->ctx->stream;
+    return launch_tile(sc, rq, d_out_rgb, d_out_f32, st);
+}
+
+RT_API int rt_scene_collect(rt_scene* sc, rt_tile_stats* st) {
+    if (!sc) return fail(RT_ERR_BAD_ARG, "scene is NULL");
+    std::lock_guard<std::mutex> lk(sc->mu);
+    HIPCHK(hipSetDevice(sc->ctx->dev));
+    return collect_locked(sc, st);
+}
+
+RT_API int rt_scene_render_tile(rt_scene* sc, const rt_tile_request* rq, uint8_t* out_rgb, size_t out_len,
+                                float* out_f32, rt_tile_stats* stats) {
+    if (!sc) return fail(RT_ERR_BAD_ARG, "scene is NULL");
+    int rc = check_request(rq);
+    if (rc) return rc;
+    if (!out_rgb) return fail(RT_ERR_BAD_ARG, "out_rgb is NULL");
+    const size_t need = rt_tile_bytes(rq);
+    if (out_len < need) return fail(RT_ERR_BUFFER_TOO_SMALL, "out_len < (H/div)*W*3");
+    std::lock_guard<std::mutex> dl(sc->ctx->mu);
+    std::lock_guard<std::mutex> lk(sc->mu);
+    HIPCHK(hipSetDevice(sc->ctx->dev));
+    hipStream_t st = sc->ctx->stream;
+    if (sc->d_out_cap < need) {
+        (void)hipFree(sc->d_out);
+        sc->d_out = nullptr;
+        sc->d_out_cap = 0;
+        hipError_t e = hipMalloc(&sc->d_out, need);
+        if (e != hipSuccess) return fail(RT_ERR_OOM, "hipMalloc(strip) failed");
+        sc->d_out_cap = need;
+    }
+    if (out_f32 && sc->d_outf_cap < need * sizeof(float)) {
+        (void)hipFree(sc->d_outf);
+        sc->d_outf = nullptr;
+        sc->d_outf_cap = 0;
+        hipError_t e = hipMalloc(&sc->d_outf, need * sizeof(float));
+        if (e != hipSuccess) return fail(RT_ERR_OOM, "hipMalloc(strip f32) failed");
+        sc->d_outf_cap = need * sizeof(float);
+    }
+    // settle anything enqueued earlier so the stats of this call are its own
+    rt_tile_stats prev;
+    rc = collect_locked(sc, &prev);
+    if (rc) return rc;
+    sc->h2d_ms = prev.h2d_ms;
+    rc = launch_tile(sc, rq, sc->d_out, out_f32 ? sc->d_outf : nullptr, st);
+    if (rc) return rc;
+    EvPair ev;
+    rc = get_events(sc, ev);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(ev.a, st));
+    HIPCHK(hipMemcpyAsync(out_rgb, sc->d_out, need, hipMemcpyDeviceToHost, st));
+    if (out_f32) HIPCHK(hipMemcpyAsync(out_f32, sc->d_outf, need * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipEventRecord(ev.b, st));
+    HIPCHK(hipEventSynchronize(ev.b));
+    float d2h = 0.f;
+    HIPCHK(hipEventElapsedTime(&d2h, ev.a, ev.b));
+    sc->free_ev.push_back({ev.a, ev.b});
+    rt_tile_stats s;
+    rc = collect_locked(sc, &s);
+    if (rc) return rc;
+    s.d2h_ms = d2h;
+    if (stats) *stats = s;
+    return RT_OK;
+}
+
+RT_API int rt_render_tile(int device, const rt_tile_request* rq, const rt_sphere* sp, uint32_t ns,
+                          const rt_triangle* tr, uint32_t nt, uint8_t* out_rgb, size_t out_len, float* out_f32,
+                          rt_tile_stats* stats) {
+    int rc = check_request(rq);
+    if (rc) return rc;
+    if (!out_rgb) return fail(RT_ERR_BAD_ARG, "out_rgb is NULL");
+    if (out_len < rt_tile_bytes(rq)) return fail(RT_ERR_BUFFER_TOO_SMALL, "out_len < (H/div)*W*3");
+    rt_scene* sc = nullptr;
+    rc = rt_scene_create(device, sp, ns, tr, nt, &sc);
+    if (rc) return rc;
+    rc = rt_scene_render_tile(sc, rq, out_rgb, out_len, out_f32, stats);
+    std::string keep = g_err;
+    rt_scene_destroy(sc);
+    if (rc) g_err = keep;
+    return rc;
+}
+
+RT_API int rt_render_frame(const int* devices, int n_devices, const rt_tile_request* rq_in, const rt_sphere* sp,
+                           uint32_t ns, const rt_triangle* tr, uint32_t nt, uint8_t* out_rgb, size_t out_len,
+                           rt_tile_stats* stats) {
+    if (!rq_in) return fail(RT_ERR_BAD_ARG, "request is NULL");
+    rt_tile_request rq0 = *rq_in;
+    rq0.division_no = 0;
+    int rc = check_request(&rq0);
+    if (rc) return rc;
+    if (!out_rgb) return fail(RT_ERR_BAD_ARG, "out_rgb is NULL");
+    if (!g_init) return fail(RT_ERR_NOT_INITIALIZED, "call rt_init() first");
+    // the controller's ImageBuffer::from_vec(width, height, ..).unwrap() (controller main.rs:117-119)
+    // panics unless the strips tile the frame exactly
+    if (rq0.height % rq0.divisions != 0) return fail(RT_ERR_FRAME_SIZE, "height % divisions != 0");
+    const size_t strip = rt_tile_bytes(&rq0);
+    if (out_len < strip * rq0.divisions) return fail(RT_ERR_BUFFER_TOO_SMALL, "out_len < H*W*3");
+    std::vector<int> devs;
+    if (devices && n_devices > 0)
+        devs.assign(devices, devices + n_devices);
+    else
+        for (size_t d = 0; d < g_ctx.size(); d++) devs.push_back((int)d);
+    for (int d : devs)
+        if (d < 0 || d >= (int)g_ctx.size()) return fail(RT_ERR_BAD_DEVICE, "bad device ordinal");
+    const int nd = (int)devs.size();
+    std::vector<int> rcs(nd, RT_OK);
+    std::vector<std::string> errs(nd);
+    std::vector<rt_tile_stats> sts(nd);
+    // one host thread + one stream per device; strip k -> devs[k % nd]  (controller main.rs:47-75
+    // fires one request per division; Docker DNS round-robins them over the slaves)
+    auto work = [&](int w) {
+        std::memset(&sts[w], 0, sizeof(rt_tile_stats));
+        rt_scene* sc = nullptr;
+        int r = rt_scene_create(devs[w], sp, ns, tr, nt, &sc);   // world uploaded once per device per job
+        if (r) {
+            rcs[w] = r;
+            errs[w] = g_err;
+            return;
+        }
+        for (uint32_t k = (uint32_t)w; k < rq0.divisions; k += (uint32_t)nd) {
+            rt_tile_request rq = rq0;
+            rq.division_no = k;
+            rt_tile_stats s;
+            // stitch by division_no: strip k lands at byte offset k * strip (controller main.rs:109-115)
+            r = rt_scene_render_tile(sc, &rq, out_rgb + (size_t)k * strip, strip, nullptr, &s);
+            if (r) {
+                rcs[w] = r;
+                errs[w] = g_err;
+                break;
+            }
+            sts[w].ray_segments += s.ray_segments;
+            sts[w].primary_rays += s.primary_rays;
+            sts[w].broad_candidates += s.broad_candidates;
+            sts[w].exact_fallbacks += s.exact_fallbacks;
+            sts[w].kernel_ms += s.kernel_ms;
+            sts[w].h2d_ms += s.h2d_ms;
+            sts[w].d2h_ms += s.d2h_ms;
+            sts[w].n_launches += s.n_launches;
+        }
+        rt_scene_destroy(sc);
+    };
+    std::vector<std::thread> th;
+    for (int w = 0; w < nd; w++) th.emplace_back(work, w);
+    for (auto& t : th) t.join();
+    rt_tile_stats tot;
+    std::memset(&tot, 0, sizeof tot);
+    for (int w = 0; w < nd; w++) {
+        if (rcs[w]) return fail(rcs[w], errs[w]);
+        tot.ray_segments += sts[w].ray_segments;
+        tot.primary_rays += sts[w].primary_rays;
+        tot.broad_candidates += sts[w].broad_candidates;
+        tot.exact_fallbacks += sts[w].exact_fallbacks;
+        tot.kernel_ms = std::max(tot.kernel_ms, sts[w].kernel_ms);   // devices run concurrently
+        tot.h2d_ms = std::max(tot.h2d_ms, sts[w].h2d_ms);
+        tot.d2h_ms = std::max(tot.d2h_ms, sts[w].d2h_ms);
+        tot.n_launches += sts[w].n_launches;
+    }
+    if (stats) *stats = tot;
+    return RT_OK;
+}
+
+}  // extern "C"

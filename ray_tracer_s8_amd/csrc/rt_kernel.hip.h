@@ -1,0 +1,500 @@
+// rt_kernel.hip.h — gfx950 path-trace tile kernel (device code).
+//
+// One work-item per pixel of a strip; a wave64 owns an 8x8 pixel tile, a 256-thread
+// workgroup a 16x16 tile.  The whole per-pixel loop of the reference slave runs inside
+// the work-item: thin-lens ray generation (camera.rs:109-129), closest hit over the
+// primitive list (shapes/mod.rs:158-191), shade + bounce (main.rs:108-146), sample
+// mean, gamma and RGB8 quantise (main.rs:73-81, color.rs:13-19).
+//
+// Arithmetic contract: every value that reaches the image is computed with the SAME
+// IEEE-754 binary32 operations in the SAME order as the reference (see oracle/rt_oracle.cpp):
+// this file must be compiled with -ffp-contract=off and correctly rounded sqrt/div
+// (hipcc default).  FMA is used only where written explicitly (__builtin_fmaf) and
+// only inside the conservative broad phase, whose value never reaches the image.
+//
+// Structure (DESIGN.md "Kernel"):
+//   * persistent lanes: a lane whose path ends starts its next sample at once, so the
+//     sphere scan runs with a nearly full EXEC mask until the pixel's spp are done;
+//   * broad phase: wave-uniform LDS broadcast reads of (cx,cy,cz,r^2), 12 VALU ops per
+//     ray-sphere pair, conservative "line misses inflated sphere" test; survivors go to
+//     a per-lane candidate list in LDS, in index order;
+//   * narrow phase: the reference's exact root computation (sphere.rs:42-47 +
+//     roots::find_roots_quadratic + shapes/mod.rs:106-129) on the candidates only;
+//   * scenes larger than one LDS chunk are streamed chunk by chunk through LDS
+//     (STREAMED=true), workgroup-synchronously.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rtk {
+
+constexpr int BLOCK = 256;       // 4 waves
+constexpr int TILE_W = 16;       // workgroup tile (2x2 waves of 8x8 pixels)
+constexpr int TILE_H = 16;
+constexpr int MAXC = 16;         // candidate list slots per lane (per chunk)
+constexpr int CHUNK = 4096;      // spheres per LDS chunk (64 KiB of float4)
+constexpr int UNROLL = 8;        // broad-phase unroll; chunk sizes are padded to this
+
+struct KParams {
+    uint32_t W, H, Hs, y0;       // image, strip rows, first global row of the strip
+    uint32_t spp, depth;         // samples per pixel; ray_color entry depth = max_bounces+1
+    uint32_t n_sph, n_sph_pad;   // spheres, padded to UNROLL with never-hit dummies
+    uint32_t n_tri;
+    uint32_t chunk;              // spheres per LDS chunk actually used (multiple of UNROLL)
+    uint32_t n_chunks;
+    uint32_t flags;
+    uint32_t path32;             // 1: path stack entries are u32, 0: u16
+    uint32_t lds_cand_off;       // byte offsets into dynamic LDS
+    uint32_t lds_path_off;
+    uint64_t seed;
+    float org[3], llc[3], hor[3], ver[3];   // Camera::new (camera.rs:19-47), host-computed
+    float lens_radius, focus_distance;
+    float u_den, v_den;          // aspect*H_f - 1, H_f - 1 (camera.rs:115-117)
+    float t_min, t_max;
+    float spp_f;
+    const float4* geom;          // [n_sph_pad] (cx,cy,cz, RN(r*r))
+    const float4* mat;           // [n_sph+n_tri] (albedo r,g,b, roughness)
+    const float* emis;           // [n_sph+n_tri]
+    const float* tri;            // [n_tri*9] a,b,c
+    uint8_t* out_rgb;            // [Hs*W*3]
+    float* out_f32;              // optional [Hs*W*3]
+    unsigned long long* counters;// [4] segments, candidates, fallbacks, (spare)
+};
+
+// ------------------------------------------------------------------ vector helpers
+struct V3 {
+    float x, y, z;
+};
+__device__ __forceinline__ V3 mk(float x, float y, float z) { return V3{x, y, z}; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 operator*(float s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
+__device__ __forceinline__ V3 operator*(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ V3 operator/(V3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
+// glam sse2 dot3 order: (x*x' + y*y') + z*z'
+__device__ __forceinline__ float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ float vlength(V3 a) { return __builtin_sqrtf(dot(a, a)); }
+__device__ __forceinline__ V3 normalize(V3 a) { return a / vlength(a); }   // glam normalize: divide
+__device__ __forceinline__ bool try_normalize(V3 a, V3& out) {            // glam try_normalize
+    float rcp = 1.0f / __builtin_sqrtf(dot(a, a));
+    if (rcp > 0.0f && rcp < __builtin_inff()) {   // is_finite() && > 0
+        out = a * rcp;
+        return true;
+    }
+    return false;
+}
+__device__ __forceinline__ V3 normalize_or_zero(V3 a) {
+    V3 r;
+    return try_normalize(a, r) ? r : mk(0.f, 0.f, 0.f);
+}
+__device__ __forceinline__ V3 cross(V3 a, V3 b) {
+    return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+
+// ------------------------------------------------------------------ RNG: rand 0.8.5 SmallRng
+struct Rng {
+    uint64_t s0, s1, s2, s3;
+};
+__device__ __forceinline__ uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+__device__ __forceinline__ uint32_t next_u32(Rng& r) {   // xoshiro256++ next_u64 >> 32
+    uint64_t result = rotl64(r.s0 + r.s3, 23) + r.s0;
+    uint64_t t = r.s1 << 17;
+    r.s2 ^= r.s0;
+    r.s3 ^= r.s1;
+    r.s1 ^= r.s2;
+    r.s0 ^= r.s3;
+    r.s2 ^= t;
+    r.s3 = rotl64(r.s3, 45);
+    return (uint32_t)(result >> 32);
+}
+__device__ __forceinline__ uint64_t splitmix_mix(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+constexpr uint64_t PHI = 0x9e3779b97f4a7c15ull;
+__device__ __forceinline__ Rng seed_pixel(uint64_t job_seed, uint64_t pixel_index) {
+    uint64_t st = splitmix_mix(job_seed + (pixel_index + 1) * PHI);   // DESIGN.md "RNG"
+    Rng r;                                                              // seed_from_u64
+    st += PHI; r.s0 = splitmix_mix(st);
+    st += PHI; r.s1 = splitmix_mix(st);
+    st += PHI; r.s2 = splitmix_mix(st);
+    st += PHI; r.s3 = splitmix_mix(st);
+    return r;
+}
+__device__ __forceinline__ float u01(Rng& r) {           // [1,2) mantissa trick, minus 1
+    return __uint_as_float((next_u32(r) >> 9) | 0x3f800000u) - 1.0f;
+}
+__device__ __forceinline__ float gen_range_01(Rng& r) { return u01(r) * 1.0f + 0.0f; }
+__device__ __forceinline__ float uniform_m1_1(Rng& r) { return u01(r) * 2.0f + -1.0f; }
+
+// ------------------------------------------------------------------ exact sphere test
+// sphere.rs:42-47 -> roots::find_roots_quadratic(1, b, c) -> shapes/mod.rs:106-129.
+// s = (cx,cy,cz, rr) with rr = RN(r*r).  td = 2*d.  Returns true and t when a root lies
+// in [t_min, t_max).
+__device__ __forceinline__ bool exact_sphere(V3 o, V3 td, float4 s, float t_min, float t_max, float& t_out) {
+    V3 oc = o - mk(s.x, s.y, s.z);
+    float b = dot(td, oc);
+    float len = __builtin_sqrtf(dot(oc, oc));
+    float c = len * len - s.w;
+    float disc = b * b - 4.0f * c;            // a1*a1 - _4*a2*a0, a2 = 1
+    if (disc < 0.0f) return false;
+    float x, y;
+    bool two;
+    if (disc == 0.0f) {
+        x = -b / 2.0f;
+        y = x;
+        two = false;
+    } else {
+        float sq = __builtin_sqrtf(disc);
+        float same_sign, diff_sign;
+        if (b < 0.0f) {
+            same_sign = -b + sq;
+            diff_sign = -b - sq;
+        } else {
+            same_sign = -b - sq;
+            diff_sign = -b + sq;
+        }
+        float x1, x2;
+        if (__builtin_fabsf(same_sign) > 2.0f) {
+            float a0x2 = 2.0f * c;
+            if (__builtin_fabsf(diff_sign) > 2.0f) {
+                x1 = a0x2 / same_sign;
+                x2 = a0x2 / diff_sign;
+            } else {
+                x1 = a0x2 / same_sign;
+                x2 = same_sign / 2.0f;
+            }
+        } else {
+            x1 = diff_sign / 2.0f;
+            x2 = same_sign / 2.0f;
+        }
+        if (x1 < x2) {
+            x = x1;
+            y = x2;
+        } else {
+            x = x2;
+            y = x1;
+        }
+        two = true;
+    }
+    bool xin = (x >= t_min) && (x < t_max);
+    if (!two) {
+        t_out = x;
+        return xin;
+    }
+    bool yin = (y >= t_min) && (y < t_max);
+    if (xin && yin) {
+        t_out = x < y ? x : y;
+        return true;
+    }
+    if (xin) {
+        t_out = x;
+        return true;
+    }
+    if (yin) {
+        t_out = y;
+        return true;
+    }
+    return false;
+}
+
+// mesh.rs:109-161 (two-sided Moller-Trumbore) -> Roots::One([dist]) -> shapes/mod.rs:109-115
+__device__ __forceinline__ bool exact_triangle(V3 o, V3 d, const float* __restrict__ tv, float t_min, float t_max,
+                                               float& t_out) {
+    const float EPSILON = 0.00001f;
+    V3 A = mk(tv[0], tv[1], tv[2]), B = mk(tv[3], tv[4], tv[5]), C = mk(tv[6], tv[7], tv[8]);
+    V3 a_to_b = B - A;
+    V3 a_to_c = C - A;
+    V3 u_vec = cross(d, a_to_c);
+    float det = dot(a_to_b, u_vec);
+    if (det < EPSILON && det > -EPSILON) return false;
+    float inv_det = 1.0f / det;
+    V3 a_to_origin = o - A;
+    float u = dot(a_to_origin, u_vec) * inv_det;
+    if (!(u >= 0.0f && u <= 1.0f)) return false;
+    V3 v_vec = cross(a_to_origin, a_to_b);
+    float v = dot(d, v_vec) * inv_det;
+    if (v < 0.0f || u + v > 1.0f) return false;
+    float dist = dot(a_to_c, v_vec) * inv_det;
+    if (!(dist > EPSILON)) return false;
+    t_out = dist;
+    return (dist >= t_min) && (dist < t_max);
+}
+
+// closest-hit bookkeeping: min_by on |P - origin|, first minimum wins, NaN keeps the
+// running one (shapes/mod.rs:177-182)
+struct Hit {
+    int idx;
+    float dist;
+    V3 p;
+};
+__device__ __forceinline__ void consider(Hit& h, int idx, V3 o, V3 d, float t) {
+    V3 p = o + t * d;                    // Ray::at (ray.rs:147-149)
+    float dist = vlength(p - o);
+    if (h.idx < 0 || h.dist > dist) {
+        h.idx = idx;
+        h.dist = dist;
+        h.p = p;
+    }
+}
+
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// Rust `as u8` from f32: truncate, saturate, NaN -> 0
+__device__ __forceinline__ uint8_t f32_as_u8(float v) {
+    if (!(v == v)) return 0;
+    if (v <= 0.0f) return 0;
+    if (v >= 255.0f) return 255;
+    return (uint8_t)(int)v;
+}
+
+// ------------------------------------------------------------------ the kernel
+template <bool STREAMED>
+__global__ __launch_bounds__(BLOCK) void rt_tile_kernel(const KParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    float4* lgeom = reinterpret_cast<float4*>(lds_raw);
+    uint16_t* lcand = reinterpret_cast<uint16_t*>(lds_raw + p.lds_cand_off);
+    unsigned char* lpath = lds_raw + p.lds_path_off;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const uint32_t px = blockIdx.x * TILE_W + (wave & 1) * 8 + (lane & 7);
+    const uint32_t pyl = blockIdx.y * TILE_H + (wave >> 1) * 8 + (lane >> 3);   // row in strip
+    bool active = (px < p.W) && (pyl < p.Hs);
+
+    if (!STREAMED) {
+        // resident scene: stage the whole primitive list into LDS once
+        for (uint32_t i = tid; i < p.n_sph_pad; i += BLOCK) lgeom[i] = p.geom[i];
+        __syncthreads();
+    }
+
+    const uint32_t yg = p.y0 + pyl;                 // main.rs:66-68
+    const float xf = (float)px;
+    const float ycf = (float)(p.H - yg - 1);        // main.rs:71
+    Rng rng = seed_pixel(p.seed, (uint64_t)yg * p.W + px);
+    const V3 corg = mk(p.org[0], p.org[1], p.org[2]);
+    const V3 llc = mk(p.llc[0], p.llc[1], p.llc[2]);
+    const V3 hor = mk(p.hor[0], p.hor[1], p.hor[2]);
+    const V3 ver = mk(p.ver[0], p.ver[1], p.ver[2]);
+    const bool exact_scan = (p.flags & 1u) != 0;
+    const float KM = 1.0f - 0x1p-17f;               // broad-phase margin
+
+    float sum_r = 0.f, sum_g = 0.f, sum_b = 0.f;
+    uint32_t s_idx = 0;          // samples finished
+    uint32_t depth_left = 0, k = 0;
+    bool need_ray = true;
+    V3 o = mk(0, 0, 0), d = mk(0, 0, 0);
+    unsigned long long n_seg = 0, n_cand = 0, n_fall = 0;
+
+    for (;;) {
+        if (active && need_ray) {
+            if (s_idx == p.spp) {
+                active = false;
+            } else {
+                // ---- Camera::get_ray (camera.rs:109-129); RNG draw order is normative
+                float a, bq;
+                for (;;) {                                   // UnitDisc
+                    a = uniform_m1_1(rng);
+                    bq = uniform_m1_1(rng);
+                    if (a * a + bq * bq <= 1.0f) break;
+                }
+                V3 offset = mk(a * p.lens_radius, bq * p.lens_radius, 0.0f);
+                float u = (xf + gen_range_01(rng)) / p.u_den;
+                float v = (ycf + gen_range_01(rng)) / p.v_den;
+                V3 dir0 = normalize_or_zero(llc + u * hor + v * ver - corg);
+                V3 d1 = normalize(dir0);                     // Ray::new re-normalises (ray.rs:134)
+                V3 focal_point = corg + p.focus_distance * d1;
+                o = corg + offset;
+                d = normalize(normalize_or_zero(focal_point - o));
+                depth_left = p.depth;
+                k = 0;
+                need_ray = false;
+            }
+        }
+        if (STREAMED) {
+            if (!__syncthreads_or(active ? 1 : 0)) break;
+        } else {
+            if (!active) break;
+        }
+
+        // ================= closest hit (shapes/mod.rs:158-191) =================
+        Hit h;
+        h.idx = -1;
+        h.dist = 0.f;
+        h.p = mk(0, 0, 0);
+        const V3 td = 2.0f * d;                              // (2f32 * ray.direction), sphere.rs:44
+        if (active) n_seg++;
+
+        for (uint32_t ch = 0; ch < p.n_chunks; ch++) {
+            const uint32_t base = ch * p.chunk;
+            const uint32_t cn = min(p.chunk, p.n_sph_pad - base);   // multiple of UNROLL
+            if (STREAMED) {
+                __syncthreads();
+                for (uint32_t i = tid; i < cn; i += BLOCK) lgeom[i] = p.geom[base + i];
+                __syncthreads();
+            }
+            if (active) {
+                if (exact_scan) {
+                    for (uint32_t j = 0; j < cn; j++) {
+                        float t;
+                        if (exact_sphere(o, td, lgeom[j], p.t_min, p.t_max, t)) consider(h, (int)(base + j), o, d, t);
+                    }
+                } else {
+                    // ---- broad phase: conservative "line misses sphere" rejection.
+                    // t = b'^2 + rr - L2*(1-2^-17) with b' = d.oc, L2 = |oc|^2, FMA allowed:
+                    // the value only selects candidates, the narrow phase decides.
+                    uint32_t cnt = 0;
+                    for (uint32_t j = 0; j < cn; j += UNROLL) {
+                        bool pass[UNROLL];
+                        bool any = false;
+#pragma unroll
+                        for (int q = 0; q < UNROLL; q++) {
+                            float4 s = lgeom[j + q];
+                            float ocx = o.x - s.x, ocy = o.y - s.y, ocz = o.z - s.z;
+                            float bb = __builtin_fmaf(d.z, ocz, __builtin_fmaf(d.y, ocy, d.x * ocx));
+                            float l2 = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, ocx * ocx));
+                            float tt = __builtin_fmaf(-l2, KM, __builtin_fmaf(bb, bb, s.w));
+                            pass[q] = !(tt < 0.0f);
+                            any |= pass[q];
+                        }
+                        if (any) {
+#pragma unroll
+                            for (int q = 0; q < UNROLL; q++) {
+                                if (pass[q]) {
+                                    if (cnt < (uint32_t)MAXC) lcand[cnt * BLOCK + tid] = (uint16_t)(j + q);
+                                    cnt++;
+                                }
+                            }
+                        }
+                    }
+                    n_cand += cnt;
+                    // ---- narrow phase: the reference's exact arithmetic, index order
+                    if (cnt <= (uint32_t)MAXC) {
+                        for (uint32_t i = 0; i < cnt; i++) {
+                            uint32_t j = lcand[i * BLOCK + tid];
+                            float t;
+                            if (exact_sphere(o, td, lgeom[j], p.t_min, p.t_max, t)) consider(h, (int)(base + j), o, d, t);
+                        }
+                    } else {
+                        n_fall++;
+                        for (uint32_t j = 0; j < cn; j++) {
+                            float t;
+                            if (exact_sphere(o, td, lgeom[j], p.t_min, p.t_max, t)) consider(h, (int)(base + j), o, d, t);
+                        }
+                    }
+                }
+            }
+        }
+        if (active) {
+            // triangles: exact test against every triangle (after the spheres in index order)
+            for (uint32_t j = 0; j < p.n_tri; j++) {
+                float t;
+                if (exact_triangle(o, d, p.tri + 9 * (size_t)j, p.t_min, p.t_max, t))
+                    consider(h, (int)(p.n_sph + j), o, d, t);
+            }
+
+            // ================= shade (main.rs:114-145) =================
+            float term_r, term_g, term_b;
+            bool finished;
+            if (h.idx >= 0) {
+                const float em = p.emis[h.idx];
+                const float4 m = p.mat[h.idx];
+                if (em > 0.0f) {                              // main.rs:116-117
+                    term_r = m.x * em;
+                    term_g = m.y * em;
+                    term_b = m.z * em;
+                    finished = true;
+                } else {
+                    V3 n;
+                    if ((uint32_t)h.idx < p.n_sph) {
+                        float4 g = p.geom[h.idx];
+                        n = normalize_or_zero(h.p - mk(g.x, g.y, g.z));             // sphere.rs:49-51
+                    } else {
+                        const float* tv = p.tri + 9 * (size_t)(h.idx - p.n_sph);
+                        V3 A = mk(tv[0], tv[1], tv[2]), B = mk(tv[3], tv[4], tv[5]), C = mk(tv[6], tv[7], tv[8]);
+                        n = normalize_or_zero(cross(A - B, A - C));                  // mesh.rs:163-165
+                    }
+                    // UnitSphere (Marsaglia), main.rs:119
+                    V3 us;
+                    for (;;) {
+                        float x1 = uniform_m1_1(rng);
+                        float x2 = uniform_m1_1(rng);
+                        float sm = x1 * x1 + x2 * x2;
+                        if (sm >= 1.0f) continue;
+                        float factor = 2.0f * __builtin_sqrtf(1.0f - sm);
+                        us = mk(x1 * factor, x2 * factor, 1.0f - 2.0f * sm);
+                        break;
+                    }
+                    V3 diffuse_dir = us + n;
+                    V3 glossy_dir = d - (2.0f * dot(d, n)) * n;                       // main.rs:120-121
+                    V3 scatter = diffuse_dir + m.w * (glossy_dir - diffuse_dir);      // main.rs:122
+                    V3 nd;
+                    if (!try_normalize(scatter, nd)) nd = n;                          // main.rs:126
+                    // push the hit on the path stack: albedo product is applied back-to-front
+                    if (p.path32)
+                        reinterpret_cast<uint32_t*>(lpath)[k * BLOCK + tid] = (uint32_t)h.idx;
+                    else
+                        reinterpret_cast<uint16_t*>(lpath)[k * BLOCK + tid] = (uint16_t)h.idx;
+                    k++;
+                    o = h.p;                                                           // origin exactly P
+                    d = normalize(nd);                                                 // Ray::new
+                    depth_left--;
+                    finished = (depth_left == 0);                                      // main.rs:109-111
+                    term_r = term_g = term_b = 0.0f;
+                }
+            } else {
+                // sky (main.rs:135-144)
+                float t = normalize_or_zero(d).y * 0.5f + 1.0f;
+                float omt = 1.0f - t;
+                term_r = 1.0f * t + 0.3f * omt;
+                term_g = 1.0f * t + 0.3f * omt;
+                term_b = 1.0f * t + 0.8f * omt;
+                finished = true;
+            }
+            if (finished) {
+                // a1 (.) (a2 (.) ( ... (ak (.) terminal))) : right-to-left (main.rs:123)
+                for (uint32_t i = k; i-- > 0;) {
+                    uint32_t idx = p.path32 ? reinterpret_cast<uint32_t*>(lpath)[i * BLOCK + tid]
+                                            : (uint32_t) reinterpret_cast<uint16_t*>(lpath)[i * BLOCK + tid];
+                    float4 m = p.mat[idx];
+                    term_r = m.x * term_r;
+                    term_g = m.y * term_g;
+                    term_b = m.z * term_b;
+                }
+                sum_r = sum_r + term_r;                      // pix_color += (main.rs:75)
+                sum_g = sum_g + term_g;
+                sum_b = sum_b + term_b;
+                s_idx++;
+                need_ray = true;
+            }
+        }
+    }
+
+    // ---- mean, gamma, quantise, store (main.rs:78-81)
+    if ((px < p.W) && (pyl < p.Hs)) {
+        float r = __builtin_sqrtf(sum_r / p.spp_f);
+        float g = __builtin_sqrtf(sum_g / p.spp_f);
+        float b = __builtin_sqrtf(sum_b / p.spp_f);
+        size_t oidx = ((size_t)pyl * p.W + px) * 3;
+        p.out_rgb[oidx + 0] = f32_as_u8(r * 255.999f);
+        p.out_rgb[oidx + 1] = f32_as_u8(g * 255.999f);
+        p.out_rgb[oidx + 2] = f32_as_u8(b * 255.999f);
+        if (p.out_f32) {
+            p.out_f32[oidx + 0] = r;
+            p.out_f32[oidx + 1] = g;
+            p.out_f32[oidx + 2] = b;
+        }
+    }
+    unsigned long long ws = wave_sum(n_seg), wc = wave_sum(n_cand), wf = wave_sum(n_fall);
+    if (lane == 0) {
+        atomicAdd(&p.counters[0], ws);
+        atomicAdd(&p.counters[1], wc);
+        atomicAdd(&p.counters[2], wf);
+    }
+}
+
+}  // namespace rtk

@@ -1,0 +1,204 @@
+"""Host-side mirror of the reference's controller<->slave surface, on top of the C-ABI.
+
+Reference (Rust, ray-tracer-slave/src/lib.rs:10-30):
+    RenderInfo { world: Vec<Object>, render_meta: RenderMeta, division_no: u32 }
+    RenderMeta { height, width, divisions, id: Uuid }
+    ImageSlice { division_no, image: Vec<u8>, id: Uuid }
+`Slave.render(info)` replaces the body of the slave's worker (main.rs:37-90); `Controller`
+replaces dispatch + assembly (controller main.rs:47-75, 109-119) with GPUs as the slaves.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import uuid
+from dataclasses import dataclass, field
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _abi
+from ._abi import TileRequest, TileStats, default_request
+from .dispatch import assemble, strips_for_worker
+
+
+@dataclass
+class RenderMeta:
+    height: int = 1080
+    width: int = 1920
+    divisions: int = 20
+    id: uuid.UUID = field(default_factory=uuid.uuid4)
+
+
+@dataclass
+class World:
+    """`Vec<Object>` split by variant: spheres first, then triangles (index order = tie order)."""
+    spheres: np.ndarray = field(default_factory=lambda: np.zeros(0, _abi.SPHERE_DTYPE))
+    triangles: np.ndarray = field(default_factory=lambda: np.zeros(0, _abi.TRIANGLE_DTYPE))
+
+    def __post_init__(self):
+        self.spheres = _abi.as_spheres(self.spheres)
+        self.triangles = _abi.as_triangles(self.triangles)
+
+
+@dataclass
+class RenderSettings:
+    """The knobs the reference hard-codes (defaults = its literals) + the job seed."""
+    spp: int = 100
+    max_bounces: int = 10
+    aperture: float = 0.1
+    focus_distance: float = 1.0
+    fov: float = float(np.float32(np.pi) / np.float32(2.0))
+    focal_length: float = 1.0
+    t_min: float = 0.001
+    t_max: float = 1000.0
+    seed: int = 0
+    flags: int = 0
+
+
+@dataclass
+class RenderInfo:
+    world: World
+    render_meta: RenderMeta
+    division_no: int
+    settings: RenderSettings = field(default_factory=RenderSettings)
+
+    def request(self) -> TileRequest:
+        s, m = self.settings, self.render_meta
+        return default_request(width=m.width, height=m.height, divisions=m.divisions, division_no=self.division_no,
+                               spp=s.spp, max_bounces=s.max_bounces, aperture=s.aperture,
+                               focus_distance=s.focus_distance, fov=s.fov, focal_length=s.focal_length,
+                               t_min=s.t_min, t_max=s.t_max, seed=s.seed, flags=s.flags)
+
+
+@dataclass
+class ImageSlice:
+    division_no: int
+    image: np.ndarray          # uint8, (H/div)*W*3, RGB, top row first
+    id: uuid.UUID
+    stats: Optional[TileStats] = None
+
+
+_initialised = False
+
+
+def init() -> int:
+    """rt_init(); returns the device count.  Raises RtError(RT_ERR_NO_DEVICE) without a GPU."""
+    global _initialised
+    lib = _abi.load()
+    n = C.c_int(0)
+    _abi.check(lib.rt_init(C.byref(n)), "rt_init")
+    _initialised = True
+    return n.value
+
+
+class Scene:
+    """rt_scene handle: the world resident in one GPU's HBM."""
+
+    def __init__(self, device: int, world: World):
+        self._lib = _abi.load()
+        if not _initialised:
+            init()
+        self.world = world
+        self.device = device
+        h = C.c_void_p()
+        _abi.check(self._lib.rt_scene_create(device, _abi.ptr(world.spheres), len(world.spheres),
+                                             _abi.ptr(world.triangles), len(world.triangles), C.byref(h)),
+                   "rt_scene_create")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.rt_scene_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def render_tile(self, req: TileRequest, want_f32: bool = False):
+        n = self._lib.rt_tile_bytes(C.byref(req))
+        out = np.empty(n, np.uint8)
+        outf = np.empty(n, np.float32) if want_f32 else None
+        st = TileStats()
+        _abi.check(self._lib.rt_scene_render_tile(self._h, C.byref(req), out.ctypes.data_as(C.c_void_p), n,
+                                                  outf.ctypes.data_as(C.c_void_p) if want_f32 else None,
+                                                  C.byref(st)), "rt_scene_render_tile")
+        return out, outf, st
+
+    def render_tile_device(self, req: TileRequest, d_out_ptr: int, out_len: int, d_f32_ptr: int = 0, stream: int = 0):
+        _abi.check(self._lib.rt_scene_render_tile_device(self._h, C.byref(req), C.c_void_p(d_out_ptr), out_len,
+                                                         C.c_void_p(d_f32_ptr) if d_f32_ptr else None,
+                                                         C.c_void_p(stream) if stream else None),
+                   "rt_scene_render_tile_device")
+
+    def collect(self) -> TileStats:
+        st = TileStats()
+        _abi.check(self._lib.rt_scene_collect(self._h, C.byref(st)), "rt_scene_collect")
+        return st
+
+
+class Slave:
+    """One GPU playing the reference's `ray-tracer-slave` worker."""
+
+    def __init__(self, device: int = 0):
+        self.device = device
+        self._scene: Optional[Scene] = None
+        self._scene_key = None
+
+    def render(self, info: RenderInfo) -> ImageSlice:
+        key = (id(info.world.spheres), id(info.world.triangles))
+        if self._scene is None or self._scene_key != key:   # the reference rebuilds per strip; we keep it resident
+            if self._scene:
+                self._scene.close()
+            self._scene = Scene(self.device, info.world)
+            self._scene_key = key
+        img, _, st = self._scene.render_tile(info.request())
+        return ImageSlice(division_no=info.division_no, image=img, id=info.render_meta.id, stats=st)
+
+    def close(self):
+        if self._scene:
+            self._scene.close()
+            self._scene = None
+
+
+class Controller:
+    """Dispatch strips to GPUs instead of docker slaves and assemble the frame."""
+
+    def __init__(self, devices: Optional[Sequence[int]] = None):
+        n = init()
+        self.devices = list(devices) if devices is not None else list(range(n))
+        self.slaves = [Slave(d) for d in self.devices]
+
+    def render_frame(self, world: World, meta: RenderMeta, settings: RenderSettings) -> np.ndarray:
+        slices = []
+        for w, slave in enumerate(self.slaves):
+            for k in strips_for_worker(meta.divisions, w, len(self.slaves)):
+                s = slave.render(RenderInfo(world, meta, k, settings))
+                slices.append((s.division_no, s.image))
+        return assemble(slices, meta.width, meta.height, meta.divisions)
+
+    def close(self):
+        for s in self.slaves:
+            s.close()
+
+
+def render_frame_native(world: World, req: TileRequest, devices: Optional[Sequence[int]] = None):
+    """rt_render_frame: the C++ dispatcher (one host thread + stream per device)."""
+    lib = _abi.load()
+    if not _initialised:
+        init()
+    n = req.width * req.height * 3
+    out = np.empty(n, np.uint8)
+    st = TileStats()
+    if devices is None:
+        dv, nd = None, 0
+    else:
+        dv, nd = (C.c_int * len(devices))(*devices), len(devices)
+    _abi.check(lib.rt_render_frame(dv, nd, C.byref(req), _abi.ptr(world.spheres), len(world.spheres),
+                                   _abi.ptr(world.triangles), len(world.triangles),
+                                   out.ctypes.data_as(C.c_void_p), n, C.byref(st)), "rt_render_frame")
+    return out.reshape(req.height, req.width, 3), st

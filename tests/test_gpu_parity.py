@@ -1,0 +1,151 @@
+"""GPU parity tests proper: the HIP path, called through the C-ABI, against the CPU oracle
+on identical scene + seed.  Bar: bit-exact RGB8, bit-exact f32 framebuffer, equal ray-segment
+counts (integer), i.e. mean |delta| = 0 <= the 1e-5 tolerance BASELINE.json states."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import ray_tracer_s8_amd as rt
+from ray_tracer_s8_amd import _abi, scenes
+
+TOL_MEAN_ABS = 1e-5      # BASELINE.json north_star: mean per-channel |delta| <= 1e-5 vs CPU
+
+
+@pytest.fixture(scope="module")
+def ndev():
+    return rt.init()
+
+
+def _small(name, w, h, spp=None, div=1):
+    sph, rq = scenes.config(name)
+    rq.width, rq.height, rq.divisions = w, h, div
+    if spp:
+        rq.spp = spp
+    return sph, rq
+
+
+def _compare(oracle, rq, sph, tri=None, backend=0, flags=0):
+    rq = rq.copy()
+    ref_rgb, ref_f, info = oracle.render(rq, sph, tri, backend=backend, want_f32=True)
+    rq.flags = flags
+    with rt.Scene(0, rt.World(sph, tri)) as sc:
+        rgb, f, st = sc.render_tile(rq, want_f32=True)
+    mean_abs = float(np.abs(f.astype(np.float64) - ref_f.astype(np.float64)).mean())
+    assert mean_abs <= TOL_MEAN_ABS, mean_abs
+    nbad = int((rgb != ref_rgb).sum())
+    assert nbad == 0, f"{nbad} RGB8 bytes differ, mean|d|={mean_abs}"
+    assert np.array_equal(f.view(np.uint32), ref_f.view(np.uint32)), "f32 framebuffer not bit-identical"
+    assert st.ray_segments == info["ray_segments"]
+    assert st.primary_rays == (rq.height // rq.divisions) * rq.width * rq.spp
+    return st
+
+
+def test_c1_single_sphere(ndev, oracle):
+    sph, rq = scenes.config("c1")
+    _compare(oracle, rq, sph)
+
+
+def test_c2_cornell_small(ndev, oracle):
+    sph, rq = _small("c2", 480, 270)
+    st = _compare(oracle, rq, sph)
+    assert st.exact_fallbacks == 0
+
+
+def test_c3_rand1024_small(ndev, oracle):
+    sph, rq = _small("c3", 240, 136, spp=4)
+    _compare(oracle, rq, sph)
+
+
+def test_exact_scan_flag_equals_filter(ndev, oracle):
+    sph, rq = _small("c3", 240, 136, spp=2)
+    a = _compare(oracle, rq, sph, flags=0)
+    b = _compare(oracle, rq, sph, flags=rt.RT_FLAG_EXACT_SCAN)
+    assert a.ray_segments == b.ray_segments
+    assert b.broad_candidates == 0
+
+
+def test_ragged_sizes_and_strips(ndev, oracle):
+    # W, Hs not multiples of the 16x16 tile; height % divisions != 0 (slave renders floor(H/div) rows)
+    sph, rq = _small("c2", 203, 131, spp=2, div=3)
+    for k in range(3):
+        rq.division_no = k
+        _compare(oracle, rq, sph)
+
+
+def test_empty_world_is_sky(ndev, oracle):
+    rq = _abi.default_request(width=64, height=48, divisions=1, spp=2, max_bounces=3, seed=7)
+    _compare(oracle, rq, None)
+
+
+def test_depth_zero_bounces(ndev, oracle):
+    sph, rq = _small("c2", 160, 90, spp=2)
+    rq.max_bounces = 0
+    _compare(oracle, rq, sph)
+
+
+def test_streamed_scene_larger_than_lds(ndev, oracle):
+    sph = scenes.rand65536(n=9000)          # > 4096: streamed through LDS chunks
+    rq = _abi.default_request(width=96, height=64, divisions=1, spp=2, max_bounces=4, seed=99)
+    _compare(oracle, rq, sph)
+
+
+def test_triangles_mixed_scene(ndev, oracle):
+    sph, tri = scenes.quad_room()
+    rq = _abi.default_request(width=160, height=96, divisions=1, spp=4, max_bounces=5, seed=5)
+    _compare(oracle, rq, sph, tri)
+
+
+def test_strips_equal_whole_frame(ndev):
+    # size-independent property: per-pixel RNG streams => stitched strips == one-strip frame
+    sph, rq = _small("c2", 320, 180, spp=2, div=1)
+    with rt.Scene(0, rt.World(sph)) as sc:
+        whole, _, _ = sc.render_tile(rq)
+        rq.divisions = 6
+        parts = []
+        for k in range(6):
+            rq.division_no = k
+            parts.append(sc.render_tile(rq)[0])
+    assert np.array_equal(np.concatenate(parts), whole)
+
+
+def test_render_frame_dispatcher(ndev):
+    sph, rq = _small("c2", 320, 180, spp=2, div=6)
+    img, st = rt.render_frame_native(rt.World(sph), rq)
+    rq1 = rq.copy()
+    rq1.divisions = 1
+    with rt.Scene(0, rt.World(sph)) as sc:
+        whole, _, st1 = sc.render_tile(rq1)
+    assert np.array_equal(img.reshape(-1), whole)
+    assert st.ray_segments == st1.ray_segments
+    assert st.n_launches == 6
+
+
+def test_error_paths(ndev):
+    lib = _abi.load()
+    sph, rq = _small("c1", 64, 64)
+    out = np.zeros(64 * 64 * 3, np.uint8)
+    st = _abi.TileStats()
+    bad = rq.copy(); bad.division_no = 1
+    assert lib.rt_render_tile(0, C.byref(bad), _abi.ptr(sph), 1, None, 0, _abi.ptr(out), out.size, None, C.byref(st)) == _abi.RT_ERR_BAD_ARG
+    assert lib.rt_render_tile(0, C.byref(rq), _abi.ptr(sph), 1, None, 0, _abi.ptr(out), 10, None, C.byref(st)) == _abi.RT_ERR_BUFFER_TOO_SMALL
+    assert lib.rt_render_tile(99, C.byref(rq), _abi.ptr(sph), 1, None, 0, _abi.ptr(out), out.size, None, C.byref(st)) == _abi.RT_ERR_BAD_DEVICE
+    bad = rq.copy(); bad.max_bounces = 1000
+    assert lib.rt_render_tile(0, C.byref(bad), _abi.ptr(sph), 1, None, 0, _abi.ptr(out), out.size, None, C.byref(st)) == _abi.RT_ERR_LIMIT
+    fr = rq.copy(); fr.height = 65; fr.divisions = 2
+    big = np.zeros(65 * 64 * 3, np.uint8)
+    assert lib.rt_render_frame(None, 0, C.byref(fr), _abi.ptr(sph), 1, None, 0, _abi.ptr(big), big.size, C.byref(st)) == _abi.RT_ERR_FRAME_SIZE
+    assert lib.rt_last_error().decode() != ""
+
+
+def test_determinism_and_seed(ndev):
+    sph, rq = _small("c3", 128, 72, spp=2)
+    with rt.Scene(0, rt.World(sph)) as sc:
+        a = sc.render_tile(rq)[0]
+        b = sc.render_tile(rq)[0]
+        rq.seed += 1
+        c = sc.render_tile(rq)[0]
+    assert np.array_equal(a, b)
+    assert not np.array_equal(a, c)
