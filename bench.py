@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: Mrays/s of the HIP tile renderer on BASELINE config c3
+(1024 random spheres, 3840x2160, 8 spp, depth 8), strips sharded over N GPUs.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic input: every rank renders the
+strips it owns of the job (N frames of c3 at N GPUs — weak scaling, unit (frame f, strip d) goes
+to rank (f + d) % N, no collective on the data path).  The scene is resident in HBM before
+the timed region; output strips are written to HBM.  Timing: barrier + synchronize on both
+sides of exactly K steps, MAX over ranks.  value = ray segments of all ranks / that time.
+
+Also reported in the same JSON line:
+  roofline      the dominant kernel against the FP32 VALU peak with SURVEY §8(d)'s algorithmic
+                20*N flops per ray segment; avg launch duration from HIP events recorded by the
+                library on the stream the kernel runs on
+  cpu_baseline  the CPU oracle (BVH back-end = the reference's algorithm) timed on this box's
+                host cores on a bounded sample, rank 0 at N=1 only.  A baseline, not the target.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+PEAK_FP32_VALU_TFLOPS = 157.3      # MI355X_MICROARCH.md: peak FP32 vector (FMA = 2 flop)
+PEAK_HBM_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FLOPS_PER_TEST = 20                # faithful ray-sphere test = 20 flop + 1 sqrt
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "c5"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-scale", type=int, default=4, help="CPU baseline renders the frame at 1/scale resolution")
+    ap.add_argument("--flags", type=int, default=0, help="rt_tile_request.flags (1 = exact scan)")
+    return ap.parse_args()
+
+
+def cpu_baseline(workload: str, scale: int):
+    """Time the oracle (test infrastructure, used here only as the reported CPU baseline)."""
+    from oracle import oracle as orc
+    from ray_tracer_s8_amd import scenes
+    sph, rq = scenes.config(workload)
+    rq.width //= scale
+    rq.height //= scale
+    rq.divisions = 1
+    rq.division_no = 0
+    threads = orc.hardware_threads()
+    _, _, info = orc.render(rq, sph, backend=1, nthreads=threads)
+    secs = info["render_ms"] / 1e3
+    return {
+        "value": info["ray_segments"] / secs / 1e6,
+        "unit": "Mrays/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": (f"{workload} scene, same spp/depth/seed, full frame at 1/{scale} resolution "
+                   f"({rq.width}x{rq.height}); C++ oracle with the reference's SAH-BVH candidate filter, "
+                   f"rows over all host threads; {info['ray_segments']} ray segments in {secs:.2f} s "
+                   f"(+{info['bvh_build_ms']:.1f} ms BVH build); omits the Rust slave's per-ray heap "
+                   "allocations, so optimistic for the reference"),
+        "cpu_seconds": secs * threads,
+    }
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1 and args.gpus > 1:
+        # not under torchrun: start the ranks as children and exit with their code
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29517"),
+               str(Path(__file__).resolve())] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    import torch
+    import torch.distributed as dist
+
+    import ray_tracer_s8_amd as rt
+    from ray_tracer_s8_amd import scenes
+    from ray_tracer_s8_amd.dispatch import job_shards
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    n_dev = rt.init()
+    assert local_rank < n_dev
+    sph, rq0 = scenes.config(args.workload)
+    rq0.flags = args.flags
+    n_frames = world                                   # weak scaling: one frame of work per GPU
+    units = job_shards(n_frames, rq0.divisions, rank, world)
+    strip_bytes = (rq0.height // rq0.divisions) * rq0.width * 3
+    out = torch.empty(len(units) * strip_bytes, dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream   # kernels and torch.cuda.synchronize share it
+    scene = rt.Scene(local_rank, rt.World(sph))        # world resident in HBM before timing
+
+    reqs = []
+    for (f, d) in units:
+        r = rq0.copy()
+        r.division_no = d
+        r.seed = rq0.seed + f
+        reqs.append(r)
+
+    def step():
+        for i, r in enumerate(reqs):
+            scene.render_tile_device(r, out.data_ptr() + i * strip_bytes, strip_bytes, 0, stream)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    scene.collect()                                    # drop warm-up counters / events
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    st = scene.collect()
+
+    elapsed = t1 - t0
+    segs = float(st.ray_segments)
+    prim = float(st.primary_rays)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        c = torch.tensor([segs, prim], dtype=torch.float64, device="cuda")
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        segs, prim = float(c[0].item()), float(c[1].item())
+
+    if rank == 0:
+        n_sph = len(sph)
+        launches = max(st.n_launches, 1)
+        avg_launch_s = st.kernel_ms / 1e3 / launches
+        segs_per_launch = float(st.ray_segments) / launches
+        achieved_tflops = segs_per_launch * FLOPS_PER_TEST * n_sph / avg_launch_s / 1e12
+        hbm_bytes_per_launch = strip_bytes + 36 * n_sph / max(len(reqs), 1)
+        traffic = None
+        tp = ROOT / "profiles" / "hbm_traffic.json"
+        if tp.exists():
+            try:
+                traffic = json.loads(tp.read_text()).get(args.workload, {}).get("bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "Mrays/sec @ 4K/8spp 1024-sphere" if args.workload == "c3" else f"Mrays/sec @ {args.workload}",
+            "value": segs / elapsed / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.workload}: {n_sph} spheres, {rq0.width}x{rq0.height}, {rq0.spp} spp, "
+                            f"depth {rq0.max_bounces}, {rq0.divisions} strips/frame, {n_frames} frame(s) "
+                            f"sharded by strip over {world} GPU(s)",
+                "rays": "ray segments (primary + secondary closest-hit queries)",
+                "mprimary_per_s": prim / elapsed / 1e6,
+                "segments_per_primary": segs / prim,
+                "exact_scan": bool(args.flags & 1),
+            },
+            "roofline": {
+                "bound": "valu",
+                "achieved": achieved_tflops,
+                "peak": PEAK_FP32_VALU_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved_tflops / PEAK_FP32_VALU_TFLOPS,
+                "traffic": traffic,
+                "kernel": "rtk::rt_tile_kernel",
+                "avg_launch_ms": avg_launch_s * 1e3,
+                "launches": launches,
+                "algorithmic_flops_per_launch": segs_per_launch * FLOPS_PER_TEST * n_sph,
+                "note": "SURVEY 8(d): neither HBM nor MFMA binds this path; FP32 VALU does. "
+                        "achieved = ray segments/launch x 20 flop x N spheres / HIP-event launch time",
+                "hbm": {
+                    "algorithmic_bytes_per_launch": hbm_bytes_per_launch,
+                    "achieved_GBs": hbm_bytes_per_launch / avg_launch_s / 1e9,
+                    "peak_GBs": PEAK_HBM_GBS,
+                    "frac": hbm_bytes_per_launch / avg_launch_s / 1e9 / PEAK_HBM_GBS,
+                },
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_scale)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+
+    scene.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
