@@ -117,9 +117,18 @@ def main():
         r.seed = rq0.seed + f
         reqs.append(r)
 
+    out_ptrs = [out.data_ptr() + i * strip_bytes for i in range(len(reqs))]
+    # all strips owned by this rank that share a frame seed go out as one batched launch
+    groups = {}
+    for r, ptr in zip(reqs, out_ptrs):
+        groups.setdefault(r.seed, ([], []))
+        groups[r.seed][0].append(r)
+        groups[r.seed][1].append(ptr)
+    batches = [(rs, ps) for rs, ps in groups.values()]
+
     def step():
-        for i, r in enumerate(reqs):
-            scene.render_tile_device(r, out.data_ptr() + i * strip_bytes, strip_bytes, 0, stream)
+        for rs, ps in batches:
+            scene.render_tiles_device(rs, ps, strip_bytes, stream)
 
     def barrier():
         if world > 1:
@@ -156,7 +165,7 @@ def main():
         avg_launch_s = st.kernel_ms / 1e3 / launches
         segs_per_launch = float(st.ray_segments) / launches
         achieved_tflops = segs_per_launch * FLOPS_PER_TEST * n_sph / avg_launch_s / 1e12
-        hbm_bytes_per_launch = strip_bytes + 36 * n_sph / max(len(reqs), 1)
+        hbm_bytes_per_launch = strip_bytes * len(reqs) / max(len(batches), 1) + 36 * n_sph   # RGB8 out + scene in
         traffic = None
         tp = ROOT / "profiles" / "hbm_traffic.json"
         if tp.exists():
@@ -185,6 +194,8 @@ def main():
                 "mprimary_per_s": prim / elapsed / 1e6,
                 "segments_per_primary": segs / prim,
                 "exact_scan": bool(args.flags & 1),
+                "broad_candidates_per_segment": float(st.broad_candidates) / max(float(st.ray_segments), 1.0),
+                "exact_fallbacks": int(st.exact_fallbacks),
             },
             "roofline": {
                 "bound": "valu",

@@ -176,6 +176,20 @@ RT_API int rt_scene_render_tile_device(rt_scene* scene, const rt_tile_request* r
                                        void* d_out_rgb, size_t out_len,
                                        void* d_out_f32, void* hip_stream);
 
+/* Batched form: n strips of ONE frame (all fields equal except division_no and seed) are
+ * rendered by a single launch of persistent waves that pull 8x8-pixel tiles of all n strips
+ * from one queue — no per-strip launch tail.  d_out_rgb[i] receives strip i; d_out_f32 may
+ * be NULL (or an array with NULL entries).  RT_ERR_BAD_ARG if the requests differ in any
+ * frame-level field. */
+RT_API int rt_scene_render_tiles_device(rt_scene* scene, const rt_tile_request* reqs, uint32_t n,
+                                        void* const* d_out_rgb, size_t out_len_each,
+                                        void* const* d_out_f32, void* hip_stream);
+
+/* Host-buffer batched form (synchronous): one launch, then one D2H copy per strip. */
+RT_API int rt_scene_render_tiles(rt_scene* scene, const rt_tile_request* reqs, uint32_t n,
+                                 uint8_t* const* out_rgb, size_t out_len_each,
+                                 float* const* out_f32, rt_tile_stats* stats);
+
 /* Wait for all work enqueued on the scene, return accumulated counters / event time
  * since the previous collect, and reset them. */
 RT_API int rt_scene_collect(rt_scene* scene, rt_tile_stats* stats);

@@ -133,6 +133,12 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     lib.rt_scene_render_tile.restype = C.c_int
     lib.rt_scene_render_tile_device.argtypes = [vp, C.POINTER(TileRequest), vp, C.c_size_t, vp, vp]
     lib.rt_scene_render_tile_device.restype = C.c_int
+    lib.rt_scene_render_tiles_device.argtypes = [vp, C.POINTER(TileRequest), C.c_uint32, C.POINTER(vp), C.c_size_t,
+                                                 C.POINTER(vp), vp]
+    lib.rt_scene_render_tiles_device.restype = C.c_int
+    lib.rt_scene_render_tiles.argtypes = [vp, C.POINTER(TileRequest), C.c_uint32, C.POINTER(vp), C.c_size_t,
+                                          C.POINTER(vp), C.POINTER(TileStats)]
+    lib.rt_scene_render_tiles.restype = C.c_int
     lib.rt_scene_collect.argtypes = [vp, C.POINTER(TileStats)]
     lib.rt_scene_collect.restype = C.c_int
     lib.rt_render_frame.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(TileRequest), vp, C.c_uint32,

@@ -39,6 +39,7 @@ int fail(int code, const std::string& msg) {
 struct DeviceCtx {
     int dev = -1;
     hipStream_t stream = nullptr;
+    int n_cu = 0;
     std::mutex mu;   // serialises synchronous calls on one device
 };
 
@@ -56,10 +57,11 @@ struct rt_scene {
     DeviceCtx* ctx = nullptr;
     uint32_t n_sph = 0, n_sph_pad = 0, n_tri = 0;
     float4* d_geom = nullptr;
+    float4* d_geom_pk = nullptr;
     float4* d_mat = nullptr;
     float* d_emis = nullptr;
     float* d_tri = nullptr;
-    unsigned long long* d_counters = nullptr;
+    unsigned long long* d_counters = nullptr;   // [0..2] stats, [4 + slot] tile queues
     // staging for the host-buffer entry point (grown on demand)
     uint8_t* d_out = nullptr;
     size_t d_out_cap = 0;
@@ -127,14 +129,26 @@ int get_events(rt_scene* sc, EvPair& ev) {
     return RT_OK;
 }
 
-// Enqueue one strip.  Caller holds sc->mu and has the device current.
-int launch_tile(rt_scene* sc, const rt_tile_request* rq, void* d_rgb, void* d_f32, hipStream_t stream) {
+constexpr uint32_t QUEUE_SLOTS = 1024;           // uncollected launches per scene
+constexpr uint32_t COUNTER_WORDS = 4 + QUEUE_SLOTS;
+
+bool same_frame(const rt_tile_request& a, const rt_tile_request& b) {
+    return a.width == b.width && a.height == b.height && a.divisions == b.divisions && a.spp == b.spp &&
+           a.max_bounces == b.max_bounces && a.aperture == b.aperture && a.focus_distance == b.focus_distance &&
+           a.fov == b.fov && a.focal_length == b.focal_length && a.t_min == b.t_min && a.t_max == b.t_max &&
+           a.flags == b.flags;
+}
+
+// Enqueue a batch of strips of one frame (<= MAX_BATCH) as ONE launch of persistent waves.
+// Caller holds sc->mu and has the device current.
+int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* const* d_rgb, void* const* d_f32,
+                 hipStream_t stream) {
+    const rt_tile_request* rq = &rqs[0];
     rtk::KParams p;
     std::memset(&p, 0, sizeof p);
     p.W = rq->width;
     p.H = rq->height;
     p.Hs = rq->height / rq->divisions;
-    p.y0 = p.Hs * rq->division_no;
     p.spp = rq->spp;
     p.depth = rq->max_bounces + 1;
     p.n_sph = sc->n_sph;
@@ -152,24 +166,47 @@ int launch_tile(rt_scene* sc, const rt_tile_request* rq, void* d_rgb, void* d_f3
     size_t path_bytes = (size_t)p.depth * rtk::BLOCK * (p.path32 ? 4 : 2);
     size_t lds = geom_bytes + cand_bytes + path_bytes;
     if (lds > LDS_LIMIT) return fail(RT_ERR_LIMIT, "LDS budget exceeded (scene chunk + path stack)");
-    p.seed = rq->seed;
     fill_camera(rq, p);
     p.t_min = rq->t_min;
     p.t_max = rq->t_max;
     p.spp_f = (float)rq->spp;
+    p.geom_pk = sc->d_geom_pk;
     p.geom = sc->d_geom;
     p.mat = sc->d_mat;
     p.emis = sc->d_emis;
     p.tri = sc->d_tri;
-    p.out_rgb = (uint8_t*)d_rgb;
-    p.out_f32 = (float*)d_f32;
+    p.n_strips = n;
+    p.tiles_x = (p.W + 7) / 8;
+    p.tiles_per_strip = p.tiles_x * ((p.Hs + 7) / 8);
+    const uint64_t n_tiles = (uint64_t)p.tiles_per_strip * n;
+    if (n_tiles > 0x7fffffffull) return fail(RT_ERR_LIMIT, "too many tiles in one launch");
+    p.n_tiles = (uint32_t)n_tiles;
+    for (uint32_t i = 0; i < n; i++) {
+        p.strips[i].seed = rqs[i].seed;
+        p.strips[i].rgb = (uint8_t*)d_rgb[i];
+        p.strips[i].f32 = d_f32 ? (float*)d_f32[i] : nullptr;
+        p.strips[i].y0 = p.Hs * rqs[i].division_no;
+    }
+    const uint32_t slot = (uint32_t)sc->pending.size();
+    if (slot >= QUEUE_SLOTS) return fail(RT_ERR_LIMIT, "too many uncollected launches: call rt_scene_collect()");
     p.counters = sc->d_counters;
+    p.queue = sc->d_counters + 4 + slot;
 
-    dim3 grid((p.W + rtk::TILE_W - 1) / rtk::TILE_W, (p.Hs + rtk::TILE_H - 1) / rtk::TILE_H);
-    dim3 block(rtk::BLOCK);
+    // persistent grid: as many workgroups as the chip holds at this LDS/VGPR budget
+    int per_cu = 0;
+    if (streamed)
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rtk::rt_tile_kernel<true>, rtk::BLOCK, lds));
+    else
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rtk::rt_tile_kernel<false>, rtk::BLOCK, lds));
+    if (per_cu < 1) per_cu = 1;
+    uint32_t blocks = (uint32_t)sc->ctx->n_cu * (uint32_t)per_cu;
+    const uint32_t useful = (p.n_tiles + 3) / 4;                 // a wave needs at least one tile
+    if (blocks > useful) blocks = useful ? useful : 1;
+    dim3 grid(blocks), block(rtk::BLOCK);
     EvPair ev;
     int rc = get_events(sc, ev);
     if (rc) return rc;
+    HIPCHK(hipMemsetAsync(p.queue, 0, sizeof(unsigned long long), stream));
     HIPCHK(hipEventRecord(ev.a, stream));
     if (streamed)
         hipLaunchKernelGGL(rtk::rt_tile_kernel<true>, grid, block, lds, stream, p);
@@ -178,8 +215,14 @@ int launch_tile(rt_scene* sc, const rt_tile_request* rq, void* d_rgb, void* d_f3
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ev.b, stream));
     sc->pending.push_back({ev.a, ev.b});
-    sc->primary_rays += (uint64_t)p.Hs * p.W * p.spp;
+    sc->primary_rays += (uint64_t)p.Hs * p.W * p.spp * n;
     return RT_OK;
+}
+
+int launch_tile(rt_scene* sc, const rt_tile_request* rq, void* d_rgb, void* d_f32, hipStream_t stream) {
+    void* rgb[1] = {d_rgb};
+    void* f32[1] = {d_f32};
+    return launch_batch(sc, rq, 1, rgb, d_f32 ? f32 : nullptr, stream);
 }
 
 int collect_locked(rt_scene* sc, rt_tile_stats* st) {
@@ -279,6 +322,7 @@ RT_API int rt_init(int* n_devices) {
         DeviceCtx* c = new DeviceCtx;
         c->dev = d;
         HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        HIPCHK(hipDeviceGetAttribute(&c->n_cu, hipDeviceAttributeMultiprocessorCount, d));
         HIPCHK(hipFuncSetAttribute((const void*)rtk::rt_tile_kernel<false>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
         HIPCHK(hipFuncSetAttribute((const void*)rtk::rt_tile_kernel<true>,
@@ -331,6 +375,12 @@ RT_API int rt_scene_create(int device, const rt_sphere* sp, uint32_t ns, const r
     }
     // padding spheres can never pass either phase: rr = -inf makes every discriminant -inf
     for (uint32_t i = ns; i < sc->n_sph_pad; i++) geom[i] = make_float4(0.f, 0.f, 0.f, -INFINITY);
+    // pair layout for the packed-FP32 broad phase: (c0x,c1x,c0y,c1y) (c0z,c1z,rr0,rr1)
+    std::vector<float4> geom_pk(geom.size());
+    for (uint32_t i = 0; i + 1 < sc->n_sph_pad; i += 2) {
+        geom_pk[i] = make_float4(geom[i].x, geom[i + 1].x, geom[i].y, geom[i + 1].y);
+        geom_pk[i + 1] = make_float4(geom[i].z, geom[i + 1].z, geom[i].w, geom[i + 1].w);
+    }
     for (uint32_t i = 0; i < nt; i++) {
         std::memcpy(&tri[(size_t)i * 9], tr[i].a, 9 * sizeof(float));
         mat[ns + i] = make_float4(tr[i].albedo_r, tr[i].albedo_g, tr[i].albedo_b, tr[i].roughness);
@@ -354,16 +404,19 @@ RT_API int rt_scene_create(int device, const rt_sphere* sp, uint32_t ns, const r
         }                                                                                 \
     } while (0)
     SC_CHK(hipMalloc(&sc->d_geom, geom.size() * sizeof(float4)));
+    SC_CHK(hipMalloc(&sc->d_geom_pk, geom_pk.size() * sizeof(float4)));
     SC_CHK(hipMalloc(&sc->d_mat, mat.size() * sizeof(float4)));
     SC_CHK(hipMalloc(&sc->d_emis, emis.size() * sizeof(float)));
     SC_CHK(hipMalloc(&sc->d_tri, tri.size() * sizeof(float)));
-    SC_CHK(hipMalloc(&sc->d_counters, 4 * sizeof(unsigned long long)));
+    SC_CHK(hipMalloc(&sc->d_counters, COUNTER_WORDS * sizeof(unsigned long long)));
     SC_CHK(hipEventRecord(e0, ctx->stream));
     SC_CHK(hipMemcpyAsync(sc->d_geom, geom.data(), geom.size() * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+    SC_CHK(hipMemcpyAsync(sc->d_geom_pk, geom_pk.data(), geom_pk.size() * sizeof(float4), hipMemcpyHostToDevice,
+                          ctx->stream));
     SC_CHK(hipMemcpyAsync(sc->d_mat, mat.data(), mat.size() * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
     SC_CHK(hipMemcpyAsync(sc->d_emis, emis.data(), emis.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     SC_CHK(hipMemcpyAsync(sc->d_tri, tri.data(), tri.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    SC_CHK(hipMemsetAsync(sc->d_counters, 0, 4 * sizeof(unsigned long long), ctx->stream));
+    SC_CHK(hipMemsetAsync(sc->d_counters, 0, COUNTER_WORDS * sizeof(unsigned long long), ctx->stream));
     SC_CHK(hipEventRecord(e1, ctx->stream));
     SC_CHK(hipEventSynchronize(e1));
     SC_CHK(hipEventElapsedTime(&sc->h2d_ms, e0, e1));
@@ -387,6 +440,7 @@ RT_API void rt_scene_destroy(rt_scene* sc) {
         (void)hipEventDestroy(pr.second);
     }
     (void)hipFree(sc->d_geom);
+    (void)hipFree(sc->d_geom_pk);
     (void)hipFree(sc->d_mat);
     (void)hipFree(sc->d_emis);
     (void)hipFree(sc->d_tri);
@@ -396,17 +450,43 @@ RT_API void rt_scene_destroy(rt_scene* sc) {
     delete sc;
 }
 
-RT_API int rt_scene_render_tile_device(rt_scene* sc, const rt_tile_request* rq, void* d_out_rgb, size_t out_len,
-                                       void* d_out_f32, void* hip_stream) {
+static int check_batch(const rt_tile_request* rqs, uint32_t n) {
+    if (!rqs || n == 0) return fail(RT_ERR_BAD_ARG, "empty request batch");
+    for (uint32_t i = 0; i < n; i++) {
+        int rc = check_request(&rqs[i]);
+        if (rc) return rc;
+        if (!same_frame(rqs[0], rqs[i]))
+            return fail(RT_ERR_BAD_ARG, "batched requests must agree on every field but division_no and seed");
+    }
+    return RT_OK;
+}
+
+RT_API int rt_scene_render_tiles_device(rt_scene* sc, const rt_tile_request* rqs, uint32_t n,
+                                        void* const* d_out_rgb, size_t out_len_each, void* const* d_out_f32,
+                                        void* hip_stream) {
     if (!sc) return fail(RT_ERR_BAD_ARG, "scene is NULL");
-    int rc = check_request(rq);
+    int rc = check_batch(rqs, n);
     if (rc) return rc;
     if (!d_out_rgb) return fail(RT_ERR_BAD_ARG, "d_out_rgb is NULL");
-    if (out_len < rt_tile_bytes(rq)) return fail(RT_ERR_BUFFER_TOO_SMALL, "out_len < (H/div)*W*3");
+    for (uint32_t i = 0; i < n; i++)
+        if (!d_out_rgb[i]) return fail(RT_ERR_BAD_ARG, "d_out_rgb[i] is NULL");
+    if (out_len_each < rt_tile_bytes(&rqs[0])) return fail(RT_ERR_BUFFER_TOO_SMALL, "out_len < (H/div)*W*3");
     std::lock_guard<std::mutex> lk(sc->mu);
     HIPCHK(hipSetDevice(sc->ctx->dev));
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : sc->ctx->stream;
-    return launch_tile(sc, rq, d_out_rgb, d_out_f32, st);
+    for (uint32_t i0 = 0; i0 < n; i0 += rtk::MAX_BATCH) {
+        uint32_t m = std::min<uint32_t>(rtk::MAX_BATCH, n - i0);
+        rc = launch_batch(sc, rqs + i0, m, d_out_rgb + i0, d_out_f32 ? d_out_f32 + i0 : nullptr, st);
+        if (rc) return rc;
+    }
+    return RT_OK;
+}
+
+RT_API int rt_scene_render_tile_device(rt_scene* sc, const rt_tile_request* rq, void* d_out_rgb, size_t out_len,
+                                       void* d_out_f32, void* hip_stream) {
+    void* rgb[1] = {d_out_rgb};
+    void* f32[1] = {d_out_f32};
+    return rt_scene_render_tiles_device(sc, rq, 1, rgb, out_len, d_out_f32 ? f32 : nullptr, hip_stream);
 }
 
 RT_API int rt_scene_collect(rt_scene* sc, rt_tile_stats* st) {
@@ -416,47 +496,62 @@ RT_API int rt_scene_collect(rt_scene* sc, rt_tile_stats* st) {
     return collect_locked(sc, st);
 }
 
-RT_API int rt_scene_render_tile(rt_scene* sc, const rt_tile_request* rq, uint8_t* out_rgb, size_t out_len,
-                                float* out_f32, rt_tile_stats* stats) {
+RT_API int rt_scene_render_tiles(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, uint8_t* const* out_rgb,
+                                 size_t out_len_each, float* const* out_f32, rt_tile_stats* stats) {
     if (!sc) return fail(RT_ERR_BAD_ARG, "scene is NULL");
-    int rc = check_request(rq);
+    int rc = check_batch(rqs, n);
     if (rc) return rc;
     if (!out_rgb) return fail(RT_ERR_BAD_ARG, "out_rgb is NULL");
-    const size_t need = rt_tile_bytes(rq);
-    if (out_len < need) return fail(RT_ERR_BUFFER_TOO_SMALL, "out_len < (H/div)*W*3");
+    for (uint32_t i = 0; i < n; i++)
+        if (!out_rgb[i]) return fail(RT_ERR_BAD_ARG, "out_rgb[i] is NULL");
+    const size_t need = rt_tile_bytes(&rqs[0]);
+    if (out_len_each < need) return fail(RT_ERR_BUFFER_TOO_SMALL, "out_len < (H/div)*W*3");
+    bool want_f32 = false;
+    if (out_f32)
+        for (uint32_t i = 0; i < n; i++) want_f32 |= out_f32[i] != nullptr;
     std::lock_guard<std::mutex> dl(sc->ctx->mu);
     std::lock_guard<std::mutex> lk(sc->mu);
     HIPCHK(hipSetDevice(sc->ctx->dev));
     hipStream_t st = sc->ctx->stream;
-    if (sc->d_out_cap < need) {
+    if (sc->d_out_cap < need * n) {
         (void)hipFree(sc->d_out);
         sc->d_out = nullptr;
         sc->d_out_cap = 0;
-        hipError_t e = hipMalloc(&sc->d_out, need);
-        if (e != hipSuccess) return fail(RT_ERR_OOM, "hipMalloc(strip) failed");
-        sc->d_out_cap = need;
+        hipError_t e = hipMalloc(&sc->d_out, need * n);
+        if (e != hipSuccess) return fail(RT_ERR_OOM, "hipMalloc(strips) failed");
+        sc->d_out_cap = need * n;
     }
-    if (out_f32 && sc->d_outf_cap < need * sizeof(float)) {
+    if (want_f32 && sc->d_outf_cap < need * n * sizeof(float)) {
         (void)hipFree(sc->d_outf);
         sc->d_outf = nullptr;
         sc->d_outf_cap = 0;
-        hipError_t e = hipMalloc(&sc->d_outf, need * sizeof(float));
-        if (e != hipSuccess) return fail(RT_ERR_OOM, "hipMalloc(strip f32) failed");
-        sc->d_outf_cap = need * sizeof(float);
+        hipError_t e = hipMalloc(&sc->d_outf, need * n * sizeof(float));
+        if (e != hipSuccess) return fail(RT_ERR_OOM, "hipMalloc(strips f32) failed");
+        sc->d_outf_cap = need * n * sizeof(float);
     }
     // settle anything enqueued earlier so the stats of this call are its own
     rt_tile_stats prev;
     rc = collect_locked(sc, &prev);
     if (rc) return rc;
     sc->h2d_ms = prev.h2d_ms;
-    rc = launch_tile(sc, rq, sc->d_out, out_f32 ? sc->d_outf : nullptr, st);
-    if (rc) return rc;
+    std::vector<void*> drgb(n), df32(n);
+    for (uint32_t i = 0; i < n; i++) {
+        drgb[i] = sc->d_out + need * i;
+        df32[i] = (want_f32 && out_f32[i]) ? (void*)(sc->d_outf + need * i) : nullptr;
+    }
+    for (uint32_t i0 = 0; i0 < n; i0 += rtk::MAX_BATCH) {
+        uint32_t m = std::min<uint32_t>(rtk::MAX_BATCH, n - i0);
+        rc = launch_batch(sc, rqs + i0, m, drgb.data() + i0, want_f32 ? df32.data() + i0 : nullptr, st);
+        if (rc) return rc;
+    }
     EvPair ev;
     rc = get_events(sc, ev);
     if (rc) return rc;
     HIPCHK(hipEventRecord(ev.a, st));
-    HIPCHK(hipMemcpyAsync(out_rgb, sc->d_out, need, hipMemcpyDeviceToHost, st));
-    if (out_f32) HIPCHK(hipMemcpyAsync(out_f32, sc->d_outf, need * sizeof(float), hipMemcpyDeviceToHost, st));
+    for (uint32_t i = 0; i < n; i++) {
+        HIPCHK(hipMemcpyAsync(out_rgb[i], drgb[i], need, hipMemcpyDeviceToHost, st));
+        if (df32[i]) HIPCHK(hipMemcpyAsync(out_f32[i], df32[i], need * sizeof(float), hipMemcpyDeviceToHost, st));
+    }
     HIPCHK(hipEventRecord(ev.b, st));
     HIPCHK(hipEventSynchronize(ev.b));
     float d2h = 0.f;
@@ -468,6 +563,13 @@ RT_API int rt_scene_render_tile(rt_scene* sc, const rt_tile_request* rq, uint8_t
     s.d2h_ms = d2h;
     if (stats) *stats = s;
     return RT_OK;
+}
+
+RT_API int rt_scene_render_tile(rt_scene* sc, const rt_tile_request* rq, uint8_t* out_rgb, size_t out_len,
+                                float* out_f32, rt_tile_stats* stats) {
+    uint8_t* rgb[1] = {out_rgb};
+    float* f32[1] = {out_f32};
+    return rt_scene_render_tiles(sc, rq, 1, rgb, out_len, out_f32 ? f32 : nullptr, stats);
 }
 
 RT_API int rt_render_tile(int device, const rt_tile_request* rq, const rt_sphere* sp, uint32_t ns,
@@ -524,25 +626,22 @@ RT_API int rt_render_frame(const int* devices, int n_devices, const rt_tile_requ
             errs[w] = g_err;
             return;
         }
+        // all strips owned by this device go out as one batch (one launch per <= MAX_BATCH strips);
+        // stitch by division_no: strip k lands at byte offset k * strip (controller main.rs:109-115)
+        std::vector<rt_tile_request> rqs;
+        std::vector<uint8_t*> outs;
         for (uint32_t k = (uint32_t)w; k < rq0.divisions; k += (uint32_t)nd) {
             rt_tile_request rq = rq0;
             rq.division_no = k;
-            rt_tile_stats s;
-            // stitch by division_no: strip k lands at byte offset k * strip (controller main.rs:109-115)
-            r = rt_scene_render_tile(sc, &rq, out_rgb + (size_t)k * strip, strip, nullptr, &s);
+            rqs.push_back(rq);
+            outs.push_back(out_rgb + (size_t)k * strip);
+        }
+        if (!rqs.empty()) {
+            r = rt_scene_render_tiles(sc, rqs.data(), (uint32_t)rqs.size(), outs.data(), strip, nullptr, &sts[w]);
             if (r) {
                 rcs[w] = r;
                 errs[w] = g_err;
-                break;
             }
-            sts[w].ray_segments += s.ray_segments;
-            sts[w].primary_rays += s.primary_rays;
-            sts[w].broad_candidates += s.broad_candidates;
-            sts[w].exact_fallbacks += s.exact_fallbacks;
-            sts[w].kernel_ms += s.kernel_ms;
-            sts[w].h2d_ms += s.h2d_ms;
-            sts[w].d2h_ms += s.d2h_ms;
-            sts[w].n_launches += s.n_launches;
         }
         rt_scene_destroy(sc);
     };

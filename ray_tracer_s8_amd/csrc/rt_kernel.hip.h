@@ -1,27 +1,30 @@
 // rt_kernel.hip.h — gfx950 path-trace tile kernel (device code).
 //
-// One work-item per pixel of a strip; a wave64 owns an 8x8 pixel tile, a 256-thread
-// workgroup a 16x16 tile.  The whole per-pixel loop of the reference slave runs inside
-// the work-item: thin-lens ray generation (camera.rs:109-129), closest hit over the
-// primitive list (shapes/mod.rs:158-191), shade + bounce (main.rs:108-146), sample
-// mean, gamma and RGB8 quantise (main.rs:73-81, color.rs:13-19).
+// One work-item per pixel: a lane owns one pixel at a time and runs the reference slave's
+// whole per-pixel loop for it — thin-lens ray generation (camera.rs:109-129), closest hit
+// over the primitive list (shapes/mod.rs:158-191), shade + bounce (main.rs:108-146),
+// sample mean, gamma and RGB8 quantise (main.rs:73-81, color.rs:13-19).
 //
 // Arithmetic contract: every value that reaches the image is computed with the SAME
-// IEEE-754 binary32 operations in the SAME order as the reference (see oracle/rt_oracle.cpp):
+// IEEE-754 binary32 operations in the SAME order as the reference (oracle/rt_oracle.cpp):
 // this file must be compiled with -ffp-contract=off and correctly rounded sqrt/div
-// (hipcc default).  FMA is used only where written explicitly (__builtin_fmaf) and
-// only inside the conservative broad phase, whose value never reaches the image.
+// (hipcc default).  FMA is used only where written explicitly and only inside the
+// conservative broad phase, whose value never reaches the image.
 //
 // Structure (DESIGN.md "Kernel"):
-//   * persistent lanes: a lane whose path ends starts its next sample at once, so the
-//     sphere scan runs with a nearly full EXEC mask until the pixel's spp are done;
-//   * broad phase: wave-uniform LDS broadcast reads of (cx,cy,cz,r^2), 12 VALU ops per
-//     ray-sphere pair, conservative "line misses inflated sphere" test; survivors go to
-//     a per-lane candidate list in LDS, in index order;
+//   * persistent waves: the grid is sized to the chip, every wave pulls 8x8-pixel tiles of
+//     the requested strips from a global atomic queue; inside a wave, a lane whose pixel
+//     is finished pulls the next pixel of the wave's current tile, and a lane whose path
+//     ends starts the pixel's next sample at once — the sphere scan runs with a nearly
+//     full EXEC mask although path lengths vary from 1 to depth+1 segments;
+//   * broad phase: wave-uniform LDS broadcast reads (ds_read_b128) of sphere pairs,
+//     packed-FP32 (v_pk_fma_f32) conservative "line misses inflated sphere" test;
+//     survivors go to a per-lane candidate list in LDS, in index order;
 //   * narrow phase: the reference's exact root computation (sphere.rs:42-47 +
 //     roots::find_roots_quadratic + shapes/mod.rs:106-129) on the candidates only;
 //   * scenes larger than one LDS chunk are streamed chunk by chunk through LDS
-//     (STREAMED=true), workgroup-synchronously.
+//     (STREAMED=true), workgroup-synchronously;
+//   * one launch serves a batch of strips (same frame, any division_no / seed).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -29,14 +32,21 @@
 namespace rtk {
 
 constexpr int BLOCK = 256;       // 4 waves
-constexpr int TILE_W = 16;       // workgroup tile (2x2 waves of 8x8 pixels)
-constexpr int TILE_H = 16;
 constexpr int MAXC = 16;         // candidate list slots per lane (per chunk)
-constexpr int CHUNK = 4096;      // spheres per LDS chunk (64 KiB of float4)
+constexpr int CHUNK = 4096;      // max spheres per LDS chunk (64 KiB)
 constexpr int UNROLL = 8;        // broad-phase unroll; chunk sizes are padded to this
+constexpr int MAX_BATCH = 64;    // strips per launch
+
+struct StripDesc {
+    uint64_t seed;
+    uint8_t* rgb;                // [Hs*W*3]
+    float* f32;                  // optional [Hs*W*3]
+    uint32_t y0;                 // first global row of the strip = Hs * division_no
+    uint32_t pad;
+};
 
 struct KParams {
-    uint32_t W, H, Hs, y0;       // image, strip rows, first global row of the strip
+    uint32_t W, H, Hs;           // image size, rows per strip
     uint32_t spp, depth;         // samples per pixel; ray_color entry depth = max_bounces+1
     uint32_t n_sph, n_sph_pad;   // spheres, padded to UNROLL with never-hit dummies
     uint32_t n_tri;
@@ -46,19 +56,21 @@ struct KParams {
     uint32_t path32;             // 1: path stack entries are u32, 0: u16
     uint32_t lds_cand_off;       // byte offsets into dynamic LDS
     uint32_t lds_path_off;
-    uint64_t seed;
+    uint32_t n_strips;           // strips in this launch
+    uint32_t tiles_x, tiles_per_strip, n_tiles;   // 8x8 tiles
     float org[3], llc[3], hor[3], ver[3];   // Camera::new (camera.rs:19-47), host-computed
     float lens_radius, focus_distance;
     float u_den, v_den;          // aspect*H_f - 1, H_f - 1 (camera.rs:115-117)
     float t_min, t_max;
     float spp_f;
+    const float4* geom_pk;       // [n_sph_pad/2][2]: (c0x,c1x,c0y,c1y) (c0z,c1z,rr0,rr1)
     const float4* geom;          // [n_sph_pad] (cx,cy,cz, RN(r*r))
     const float4* mat;           // [n_sph+n_tri] (albedo r,g,b, roughness)
     const float* emis;           // [n_sph+n_tri]
     const float* tri;            // [n_tri*9] a,b,c
-    uint8_t* out_rgb;            // [Hs*W*3]
-    float* out_f32;              // optional [Hs*W*3]
-    unsigned long long* counters;// [4] segments, candidates, fallbacks, (spare)
+    unsigned long long* counters;// [0] segments [1] candidates [2] fallbacks
+    unsigned long long* queue;   // tile queue head of this launch (zeroed on the stream before it)
+    StripDesc strips[MAX_BATCH];
 };
 
 // ------------------------------------------------------------------ vector helpers
@@ -130,13 +142,13 @@ __device__ __forceinline__ float uniform_m1_1(Rng& r) { return u01(r) * 2.0f + -
 
 // ------------------------------------------------------------------ exact sphere test
 // sphere.rs:42-47 -> roots::find_roots_quadratic(1, b, c) -> shapes/mod.rs:106-129.
-// s = (cx,cy,cz, rr) with rr = RN(r*r).  td = 2*d.  Returns true and t when a root lies
-// in [t_min, t_max).
-__device__ __forceinline__ bool exact_sphere(V3 o, V3 td, float4 s, float t_min, float t_max, float& t_out) {
-    V3 oc = o - mk(s.x, s.y, s.z);
+// c = center, rr = RN(r*r).  td = 2*d.  Returns true and t when a root lies in [t_min, t_max).
+__device__ __forceinline__ bool exact_sphere(V3 o, V3 td, V3 cen, float rr, float t_min, float t_max,
+                                             float& t_out) {
+    V3 oc = o - cen;
     float b = dot(td, oc);
     float len = __builtin_sqrtf(dot(oc, oc));
-    float c = len * len - s.w;
+    float c = len * len - rr;
     float disc = b * b - 4.0f * c;            // a1*a1 - _4*a2*a0, a2 = 1
     if (disc < 0.0f) return false;
     float x, y;
@@ -252,68 +264,115 @@ __device__ __forceinline__ uint8_t f32_as_u8(float v) {
     return (uint8_t)(int)v;
 }
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+
 // ------------------------------------------------------------------ the kernel
 template <bool STREAMED>
 __global__ __launch_bounds__(BLOCK) void rt_tile_kernel(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    float4* lgeom = reinterpret_cast<float4*>(lds_raw);
+    float4* lgeom = reinterpret_cast<float4*>(lds_raw);          // pair layout, see KParams::geom_pk
+    const float* lgeomf = reinterpret_cast<const float*>(lds_raw);
     uint16_t* lcand = reinterpret_cast<uint16_t*>(lds_raw + p.lds_cand_off);
     unsigned char* lpath = lds_raw + p.lds_path_off;
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const uint32_t px = blockIdx.x * TILE_W + (wave & 1) * 8 + (lane & 7);
-    const uint32_t pyl = blockIdx.y * TILE_H + (wave >> 1) * 8 + (lane >> 3);   // row in strip
-    bool active = (px < p.W) && (pyl < p.Hs);
+    const int lane = tid & 63;
 
     if (!STREAMED) {
         // resident scene: stage the whole primitive list into LDS once
-        for (uint32_t i = tid; i < p.n_sph_pad; i += BLOCK) lgeom[i] = p.geom[i];
+        for (uint32_t i = tid; i < p.n_sph_pad; i += BLOCK) lgeom[i] = p.geom_pk[i];
         __syncthreads();
     }
 
-    const uint32_t yg = p.y0 + pyl;                 // main.rs:66-68
-    const float xf = (float)px;
-    const float ycf = (float)(p.H - yg - 1);        // main.rs:71
-    Rng rng = seed_pixel(p.seed, (uint64_t)yg * p.W + px);
     const V3 corg = mk(p.org[0], p.org[1], p.org[2]);
     const V3 llc = mk(p.llc[0], p.llc[1], p.llc[2]);
     const V3 hor = mk(p.hor[0], p.hor[1], p.hor[2]);
     const V3 ver = mk(p.ver[0], p.ver[1], p.ver[2]);
     const bool exact_scan = (p.flags & 1u) != 0;
-    const float KM = 1.0f - 0x1p-17f;               // broad-phase margin
+    const float KMf = 1.0f - 0x1p-17f;              // broad-phase margin
+    const v2f NKM = {-KMf, -KMf};
 
+    // ---- wave-uniform tile cursor (kept identical in every live lane)
+    uint32_t tile_id = 0, tile_pos = 64;
+    // ---- per-lane pixel state
+    bool have_pixel = false, retired = false, need_ray = false;
+    uint32_t px = 0, pyl = 0, strip = 0;
+    float xf = 0.f, ycf = 0.f;
+    Rng rng = {0, 0, 0, 0};
     float sum_r = 0.f, sum_g = 0.f, sum_b = 0.f;
     uint32_t s_idx = 0;          // samples finished
     uint32_t depth_left = 0, k = 0;
-    bool need_ray = true;
     V3 o = mk(0, 0, 0), d = mk(0, 0, 0);
     unsigned long long n_seg = 0, n_cand = 0, n_fall = 0;
 
     for (;;) {
-        if (active && need_ray) {
-            if (s_idx == p.spp) {
-                active = false;
-            } else {
-                // ---- Camera::get_ray (camera.rs:109-129); RNG draw order is normative
-                float a, bq;
-                for (;;) {                                   // UnitDisc
-                    a = uniform_m1_1(rng);
-                    bq = uniform_m1_1(rng);
-                    if (a * a + bq * bq <= 1.0f) break;
+        // ================= pixel acquisition: lanes pull pixels of the wave's current tile
+        {
+            bool need = !have_pixel && !retired;
+            for (;;) {
+                unsigned long long mask = __ballot(need);
+                if (mask == 0) break;
+                if (tile_pos >= 64) {                         // wave-uniform: fetch the next tile
+                    unsigned long long live = __ballot(true);
+                    uint32_t t = 0;
+                    if (lane == (int)__builtin_ctzll(live)) t = (uint32_t)atomicAdd(p.queue, 1ull);
+                    t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+                    if (t >= p.n_tiles) {                     // queue drained: needy lanes retire
+                        if (need) retired = true;
+                        break;
+                    }
+                    tile_id = t;
+                    tile_pos = 0;
                 }
-                V3 offset = mk(a * p.lens_radius, bq * p.lens_radius, 0.0f);
-                float u = (xf + gen_range_01(rng)) / p.u_den;
-                float v = (ycf + gen_range_01(rng)) / p.v_den;
-                V3 dir0 = normalize_or_zero(llc + u * hor + v * ver - corg);
-                V3 d1 = normalize(dir0);                     // Ray::new re-normalises (ray.rs:134)
-                V3 focal_point = corg + p.focus_distance * d1;
-                o = corg + offset;
-                d = normalize(normalize_or_zero(focal_point - o));
-                depth_left = p.depth;
-                k = 0;
-                need_ray = false;
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                const uint32_t avail = 64u - tile_pos;
+                const uint32_t want = (uint32_t)__builtin_popcountll(mask);
+                if (need && rank < avail) {
+                    const uint32_t pidx = tile_pos + rank;
+                    const uint32_t st = tile_id / p.tiles_per_strip;
+                    const uint32_t rem = tile_id - st * p.tiles_per_strip;
+                    const uint32_t ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+                    const uint32_t x = tx * 8 + (pidx & 7), y = ty * 8 + (pidx >> 3);
+                    if (x < p.W && y < p.Hs) {
+                        px = x;
+                        pyl = y;
+                        strip = st;
+                        const uint32_t yg = p.strips[st].y0 + y;                  // main.rs:66-68
+                        xf = (float)x;
+                        ycf = (float)(p.H - yg - 1);                              // main.rs:71
+                        rng = seed_pixel(p.strips[st].seed, (uint64_t)yg * p.W + x);
+                        sum_r = sum_g = sum_b = 0.f;
+                        s_idx = 0;
+                        have_pixel = true;
+                        need_ray = true;
+                        need = false;
+                    }
+                }
+                tile_pos += min(want, avail);
             }
+        }
+        const bool active = have_pixel;
+        if (active && need_ray) {
+            // ---- Camera::get_ray (camera.rs:109-129); RNG draw order is normative
+            float a, bq;
+            for (;;) {                                   // UnitDisc
+                a = uniform_m1_1(rng);
+                bq = uniform_m1_1(rng);
+                if (a * a + bq * bq <= 1.0f) break;
+            }
+            V3 offset = mk(a * p.lens_radius, bq * p.lens_radius, 0.0f);
+            float u = (xf + gen_range_01(rng)) / p.u_den;
+            float v = (ycf + gen_range_01(rng)) / p.v_den;
+            V3 dir0 = normalize_or_zero(llc + u * hor + v * ver - corg);
+            V3 d1 = normalize(dir0);                     // Ray::new re-normalises (ray.rs:134)
+            V3 focal_point = corg + p.focus_distance * d1;
+            o = corg + offset;
+            d = normalize(normalize_or_zero(focal_point - o));
+            depth_left = p.depth;
+            k = 0;
+            need_ray = false;
         }
         if (STREAMED) {
             if (!__syncthreads_or(active ? 1 : 0)) break;
@@ -334,37 +393,40 @@ __global__ __launch_bounds__(BLOCK) void rt_tile_kernel(const KParams p) {
             const uint32_t cn = min(p.chunk, p.n_sph_pad - base);   // multiple of UNROLL
             if (STREAMED) {
                 __syncthreads();
-                for (uint32_t i = tid; i < cn; i += BLOCK) lgeom[i] = p.geom[base + i];
+                for (uint32_t i = tid; i < cn; i += BLOCK) lgeom[i] = p.geom_pk[base + i];
                 __syncthreads();
             }
             if (active) {
-                if (exact_scan) {
-                    for (uint32_t j = 0; j < cn; j++) {
-                        float t;
-                        if (exact_sphere(o, td, lgeom[j], p.t_min, p.t_max, t)) consider(h, (int)(base + j), o, d, t);
-                    }
-                } else {
-                    // ---- broad phase: conservative "line misses sphere" rejection.
-                    // t = b'^2 + rr - L2*(1-2^-17) with b' = d.oc, L2 = |oc|^2, FMA allowed:
-                    // the value only selects candidates, the narrow phase decides.
-                    uint32_t cnt = 0;
+                uint32_t cnt = 0;
+                if (!exact_scan) {
+                    // ---- broad phase: conservative "line misses sphere" rejection on sphere pairs.
+                    // t = b'^2 + rr - L2*(1-2^-17), b' = d.oc, L2 = |oc|^2 (FMA allowed: the value
+                    // only selects candidates, the narrow phase decides).  pass = !(t < 0).
+                    const v2f ox2 = {o.x, o.x}, oy2 = {o.y, o.y}, oz2 = {o.z, o.z};
+                    const v2f dx2 = {d.x, d.x}, dy2 = {d.y, d.y}, dz2 = {d.z, d.z};
                     for (uint32_t j = 0; j < cn; j += UNROLL) {
-                        bool pass[UNROLL];
-                        bool any = false;
+                        float t[UNROLL];
 #pragma unroll
-                        for (int q = 0; q < UNROLL; q++) {
-                            float4 s = lgeom[j + q];
-                            float ocx = o.x - s.x, ocy = o.y - s.y, ocz = o.z - s.z;
-                            float bb = __builtin_fmaf(d.z, ocz, __builtin_fmaf(d.y, ocy, d.x * ocx));
-                            float l2 = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, ocx * ocx));
-                            float tt = __builtin_fmaf(-l2, KM, __builtin_fmaf(bb, bb, s.w));
-                            pass[q] = !(tt < 0.0f);
-                            any |= pass[q];
+                        for (int q = 0; q < UNROLL / 2; q++) {
+                            const float4 A = lgeom[j + 2 * q];
+                            const float4 B = lgeom[j + 2 * q + 1];
+                            const v2f cx = {A.x, A.y}, cy = {A.z, A.w}, cz = {B.x, B.y}, rr = {B.z, B.w};
+                            const v2f ocx = ox2 - cx, ocy = oy2 - cy, ocz = oz2 - cz;
+                            const v2f bb = pk_fma(dz2, ocz, pk_fma(dy2, ocy, dx2 * ocx));
+                            const v2f l2 = pk_fma(ocz, ocz, pk_fma(ocy, ocy, ocx * ocx));
+                            const v2f tt = pk_fma(l2, NKM, pk_fma(bb, bb, rr));
+                            t[2 * q] = tt.x;
+                            t[2 * q + 1] = tt.y;
                         }
-                        if (any) {
+                        // max ignores NaN; a NaN t can only come from non-finite operands, for
+                        // which the exact test reports a miss as well
+                        const float m = __builtin_fmaxf(
+                            __builtin_fmaxf(__builtin_fmaxf(t[0], t[1]), __builtin_fmaxf(t[2], t[3])),
+                            __builtin_fmaxf(__builtin_fmaxf(t[4], t[5]), __builtin_fmaxf(t[6], t[7])));
+                        if (!(m < 0.0f)) {
 #pragma unroll
                             for (int q = 0; q < UNROLL; q++) {
-                                if (pass[q]) {
+                                if (!(t[q] < 0.0f)) {
                                     if (cnt < (uint32_t)MAXC) lcand[cnt * BLOCK + tid] = (uint16_t)(j + q);
                                     cnt++;
                                 }
@@ -372,20 +434,19 @@ __global__ __launch_bounds__(BLOCK) void rt_tile_kernel(const KParams p) {
                         }
                     }
                     n_cand += cnt;
-                    // ---- narrow phase: the reference's exact arithmetic, index order
-                    if (cnt <= (uint32_t)MAXC) {
-                        for (uint32_t i = 0; i < cnt; i++) {
-                            uint32_t j = lcand[i * BLOCK + tid];
-                            float t;
-                            if (exact_sphere(o, td, lgeom[j], p.t_min, p.t_max, t)) consider(h, (int)(base + j), o, d, t);
-                        }
-                    } else {
-                        n_fall++;
-                        for (uint32_t j = 0; j < cn; j++) {
-                            float t;
-                            if (exact_sphere(o, td, lgeom[j], p.t_min, p.t_max, t)) consider(h, (int)(base + j), o, d, t);
-                        }
-                    }
+                }
+                // ---- narrow phase: the reference's exact arithmetic, ascending index order.
+                // direct = every sphere of the chunk (exact-scan flag, or candidate list overflow)
+                const bool direct = exact_scan || cnt > (uint32_t)MAXC;
+                if (!exact_scan && direct) n_fall++;
+                const uint32_t n_it = direct ? cn : cnt;
+                for (uint32_t i = 0; i < n_it; i++) {
+                    const uint32_t j = direct ? i : (uint32_t)lcand[i * BLOCK + tid];
+                    const uint32_t fo = (j >> 1) * 8 + (j & 1);
+                    const V3 cen = mk(lgeomf[fo], lgeomf[fo + 2], lgeomf[fo + 4]);
+                    const float rr = lgeomf[fo + 6];
+                    float t;
+                    if (exact_sphere(o, td, cen, rr, p.t_min, p.t_max, t)) consider(h, (int)(base + j), o, d, t);
                 }
             }
         }
@@ -470,25 +531,28 @@ __global__ __launch_bounds__(BLOCK) void rt_tile_kernel(const KParams p) {
                 sum_b = sum_b + term_b;
                 s_idx++;
                 need_ray = true;
+                if (s_idx == p.spp) {
+                    // ---- mean, gamma, quantise, store (main.rs:78-81)
+                    float r = __builtin_sqrtf(sum_r / p.spp_f);
+                    float g = __builtin_sqrtf(sum_g / p.spp_f);
+                    float b = __builtin_sqrtf(sum_b / p.spp_f);
+                    size_t oidx = ((size_t)pyl * p.W + px) * 3;
+                    uint8_t* orgb = p.strips[strip].rgb;
+                    orgb[oidx + 0] = f32_as_u8(r * 255.999f);
+                    orgb[oidx + 1] = f32_as_u8(g * 255.999f);
+                    orgb[oidx + 2] = f32_as_u8(b * 255.999f);
+                    float* of = p.strips[strip].f32;
+                    if (of) {
+                        of[oidx + 0] = r;
+                        of[oidx + 1] = g;
+                        of[oidx + 2] = b;
+                    }
+                    have_pixel = false;
+                }
             }
         }
     }
 
-    // ---- mean, gamma, quantise, store (main.rs:78-81)
-    if ((px < p.W) && (pyl < p.Hs)) {
-        float r = __builtin_sqrtf(sum_r / p.spp_f);
-        float g = __builtin_sqrtf(sum_g / p.spp_f);
-        float b = __builtin_sqrtf(sum_b / p.spp_f);
-        size_t oidx = ((size_t)pyl * p.W + px) * 3;
-        p.out_rgb[oidx + 0] = f32_as_u8(r * 255.999f);
-        p.out_rgb[oidx + 1] = f32_as_u8(g * 255.999f);
-        p.out_rgb[oidx + 2] = f32_as_u8(b * 255.999f);
-        if (p.out_f32) {
-            p.out_f32[oidx + 0] = r;
-            p.out_f32[oidx + 1] = g;
-            p.out_f32[oidx + 2] = b;
-        }
-    }
     unsigned long long ws = wave_sum(n_seg), wc = wave_sum(n_cand), wf = wave_sum(n_fall);
     if (lane == 0) {
         atomicAdd(&p.counters[0], ws);

@@ -135,6 +135,33 @@ class Scene:
                                                          C.c_void_p(stream) if stream else None),
                    "rt_scene_render_tile_device")
 
+    def render_tiles(self, reqs: Sequence[TileRequest], want_f32: bool = False):
+        """Batched: strips of one frame in ONE launch (rt_scene_render_tiles)."""
+        n = len(reqs)
+        nb = self._lib.rt_tile_bytes(C.byref(reqs[0]))
+        arr = (TileRequest * n)(*reqs)
+        outs = [np.empty(nb, np.uint8) for _ in range(n)]
+        outf = [np.empty(nb, np.float32) for _ in range(n)] if want_f32 else None
+        po = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+        pf = (C.c_void_p * n)(*[o.ctypes.data for o in outf]) if want_f32 else None
+        st = TileStats()
+        _abi.check(self._lib.rt_scene_render_tiles(self._h, arr, n, po, nb, pf, C.byref(st)), "rt_scene_render_tiles")
+        return outs, outf, st
+
+    def render_tiles_device(self, reqs: Sequence[TileRequest], d_out_ptrs: Sequence[int], out_len_each: int,
+                            stream: int = 0):
+        """Batched, asynchronous, device-resident output (rt_scene_render_tiles_device)."""
+        n = len(reqs)
+        cache = getattr(self, "_batch_cache", None)
+        key = (id(reqs), tuple(d_out_ptrs))
+        if cache is None or cache[0] != key:
+            arr = (TileRequest * n)(*reqs)
+            po = (C.c_void_p * n)(*d_out_ptrs)
+            self._batch_cache = cache = (key, arr, po)
+        _abi.check(self._lib.rt_scene_render_tiles_device(self._h, cache[1], n, cache[2], out_len_each, None,
+                                                          C.c_void_p(stream) if stream else None),
+                   "rt_scene_render_tiles_device")
+
     def collect(self) -> TileStats:
         st = TileStats()
         _abi.check(self._lib.rt_scene_collect(self._h, C.byref(st)), "rt_scene_collect")

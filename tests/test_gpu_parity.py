@@ -120,7 +120,26 @@ def test_render_frame_dispatcher(ndev):
         whole, _, st1 = sc.render_tile(rq1)
     assert np.array_equal(img.reshape(-1), whole)
     assert st.ray_segments == st1.ray_segments
-    assert st.n_launches == 6
+    assert st.n_launches == 1          # six strips, one batched launch of persistent waves
+
+
+def test_batched_strips_one_launch(ndev, oracle):
+    # strips of one frame with different seeds / division_no in one launch == strip-by-strip oracle
+    sph, rq = _small("c3", 200, 120, spp=2, div=5)
+    reqs = []
+    for k in (4, 0, 2):
+        r = rq.copy(); r.division_no = k; r.seed = rq.seed + k
+        reqs.append(r)
+    with rt.Scene(0, rt.World(sph)) as sc:
+        outs, outf, st = sc.render_tiles(reqs, want_f32=True)
+    assert st.n_launches == 1
+    segs = 0
+    for r, o, f in zip(reqs, outs, outf):
+        ref, ref_f, info = oracle.render(r, sph, want_f32=True)
+        assert np.array_equal(o, ref)
+        assert np.array_equal(f.view(np.uint32), ref_f.view(np.uint32))
+        segs += info["ray_segments"]
+    assert st.ray_segments == segs
 
 
 def test_error_paths(ndev):

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Run on the GPU box (via gpurun): kernel trace + PMC passes of the bench command.
+# usage: tools/prof.sh <tag> [bench args...]
+set -e
+TAG=${1:-r01}; shift || true
+OUT=gpurun_out/prof_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+ARGS="--steps 2 --warmup 1 --no-cpu-baseline $@"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $ARGS > $OUT/trace.log 2>&1
+echo "trace done"
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -d $OUT/pmc1 -- python3 bench.py $ARGS > $OUT/pmc1.log 2>&1
+echo "pmc1 done"
+rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD --output-format csv -d $OUT/pmc2 -- python3 bench.py $ARGS > $OUT/pmc2.log 2>&1
+echo "pmc2 done"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc3 -- python3 bench.py $ARGS > $OUT/pmc3.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc4 -- python3 bench.py $ARGS > $OUT/pmc4.log 2>&1
+echo "pmc3/4 done"
+find $OUT -name "*.csv" | head -40
