@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the CPU oracle (linear back-end).
+
+The reference (Rust) cannot run in this image, so these vectors are outputs of the
+line-traceable restatement, cross-checked by oracle/restate_np.py — they pin regressions of
+the oracle and give the GPU tests committed bytes to match.  Re-run only when the normative
+spec changes:  python tests/golden/make_golden.py
+"""
+import hashlib
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT))
+from oracle import oracle  # noqa: E402
+from ray_tracer_s8_amd import _abi, scenes  # noqa: E402
+
+HERE = Path(__file__).resolve().parent
+
+
+def cases():
+    sph, rq = scenes.config("c1")                      # BASELINE c1 at full size: 256x256, 1 spp
+    yield "c1_single_sphere_256", rq, sph, None, True
+    sph, rq = scenes.config("c2")
+    rq.width, rq.height, rq.divisions, rq.division_no = 96, 54, 3, 1
+    yield "c2_cornell_96x54_strip1of3", rq, sph, None, True
+    sph, rq = scenes.config("c3")
+    rq.width, rq.height, rq.divisions, rq.spp = 96, 54, 1, 4
+    yield "c3_rand1024_96x54", rq, sph, None, True
+    sph, tri = scenes.quad_room()
+    rq = _abi.default_request(width=80, height=48, divisions=1, spp=4, max_bounces=5, seed=5)
+    yield "quad_room_80x48", rq, sph, tri, True
+    sph = scenes.rand65536(n=9000)
+    rq = _abi.default_request(width=64, height=40, divisions=1, spp=2, max_bounces=4, seed=99)
+    yield "rand9000_streamed_64x40", rq, sph, None, True
+    # larger frames: only a checksum is stored
+    sph, rq = scenes.config("c2")
+    rq.width, rq.height, rq.divisions = 480, 270, 1
+    yield "c2_cornell_480x270_sha", rq, sph, None, False
+
+
+def req_fields(rq):
+    return {k: getattr(rq, k) for k, _ in rq._fields_}
+
+
+def main():
+    for name, rq, sph, tri, store in cases():
+        rgb, f32, info = oracle.render(rq, sph, tri, backend=0, want_f32=True)
+        sha = hashlib.sha256(rgb.tobytes()).hexdigest()
+        sha_f = hashlib.sha256(f32.tobytes()).hexdigest()
+        out = dict(request=np.array([tuple(req_fields(rq).values())],
+                                    dtype=[(k, "f8" if isinstance(v, float) else "u8") for k, v in req_fields(rq).items()]),
+                   sha256_rgb=np.array(sha), sha256_f32=np.array(sha_f), ray_segments=np.array(info["ray_segments"], dtype=np.uint64))
+        if store:
+            out["rgb"] = rgb
+        np.savez_compressed(HERE / f"{name}.npz", **out)
+        print(name, rgb.size, sha[:16], info["ray_segments"])
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,122 @@
+"""The C-ABI library loads and exports every symbol include/rt_tile.h declares (no compute
+calls: this container has no GPU), argument checks that need no device, struct layouts."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from ray_tracer_s8_amd import _abi
+
+ROOT = Path(__file__).resolve().parent.parent
+HEADER = (ROOT / "include" / "rt_tile.h").read_text()
+
+
+def declared_functions():
+    return re.findall(r"RT_API\s+[\w\s\*]+?\b(rt_\w+)\s*\(", HEADER)
+
+
+def test_header_declares_expected_surface():
+    names = declared_functions()
+    for must in ("rt_init", "rt_shutdown", "rt_strerror", "rt_last_error", "rt_render_tile", "rt_scene_create",
+                 "rt_scene_destroy", "rt_scene_render_tile", "rt_scene_render_tile_device",
+                 "rt_scene_render_tiles_device", "rt_scene_render_tiles", "rt_scene_collect", "rt_render_frame",
+                 "rt_tile_request_defaults", "rt_tile_bytes", "rt_abi_version"):
+        assert must in names, must
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _abi.load()
+    for name in declared_functions():
+        assert hasattr(lib, name), f"{name} declared in rt_tile.h but not exported by librt_s8.so"
+    assert lib.rt_abi_version() == 1
+
+
+def test_header_cites_reference_lines():
+    # every entry point names the reference code it replaces
+    for cite in ("main.rs:37-83", "main.rs:108-146", "camera.rs:109-129", "lib.rs:10-15", "sphere.rs:12-20",
+                 "mesh.rs:14-23", "controller main.rs:47-75", "shapes/mod.rs:12"):
+        assert cite in HEADER, cite
+
+
+def test_struct_layouts_match_header():
+    assert C.sizeof(_abi.TileRequest) == 64
+    assert _abi.SPHERE_DTYPE.itemsize == 36 and _abi.TRIANGLE_DTYPE.itemsize == 56
+    assert C.sizeof(_abi.TileStats) == 48
+    offs = {n: getattr(_abi.TileRequest, n).offset for n, _ in _abi.TileRequest._fields_}
+    assert offs["width"] == 0 and offs["spp"] == 16 and offs["aperture"] == 24 and offs["seed"] == 48 and offs["flags"] == 56
+
+
+def test_defaults_are_the_reference_literals():
+    lib = _abi.load()
+    r = _abi.TileRequest()
+    lib.rt_tile_request_defaults(C.byref(r))
+    p = _abi.default_request()
+    assert bytes(r) == bytes(p)
+    assert (r.width, r.height, r.divisions) == (1920, 1080, 20)       # controller main.rs:33-39
+    assert (r.spp, r.max_bounces) == (100, 10)                         # slave main.rs:39,51
+    assert np.float32(r.aperture) == np.float32(0.1) and r.focus_distance == 1.0 and r.focal_length == 1.0
+    assert np.float32(r.fov) == np.float32(np.pi) / np.float32(2)
+    assert np.float32(r.t_min) == np.float32(0.001) and r.t_max == 1000.0
+    assert lib.rt_tile_bytes(C.byref(r)) == 54 * 1920 * 3             # (1080/20)*1920*3, main.rs:53-59
+
+
+def test_strerror_and_status_codes():
+    lib = _abi.load()
+    for code in range(0, -10, -1):
+        s = lib.rt_strerror(code).decode()
+        assert s and s != "unknown status"
+    assert lib.rt_strerror(-99).decode() == "unknown status"
+
+
+def test_fails_loudly_without_device_or_init():
+    """No CPU fallback: without a device / without rt_init every compute entry point errors."""
+    lib = _abi.load()
+    n = C.c_int(-1)
+    rc = lib.rt_init(C.byref(n))
+    if rc == _abi.RT_OK:                       # running on a GPU box
+        assert n.value >= 1
+        return
+    assert rc == _abi.RT_ERR_NO_DEVICE and n.value == 0
+    assert "hipGetDeviceCount" in lib.rt_last_error().decode()
+    sph = np.zeros(1, _abi.SPHERE_DTYPE)
+    h = C.c_void_p()
+    assert lib.rt_scene_create(0, _abi.ptr(sph), 1, None, 0, C.byref(h)) == _abi.RT_ERR_NOT_INITIALIZED
+    rq = _abi.default_request(width=8, height=8, divisions=1, spp=1)
+    out = np.zeros(8 * 8 * 3, np.uint8)
+    st = _abi.TileStats()
+    assert lib.rt_render_tile(0, C.byref(rq), _abi.ptr(sph), 1, None, 0, _abi.ptr(out), out.size, None,
+                              C.byref(st)) == _abi.RT_ERR_NOT_INITIALIZED
+    assert lib.rt_render_frame(None, 0, C.byref(rq), _abi.ptr(sph), 1, None, 0, _abi.ptr(out), out.size,
+                               C.byref(st)) == _abi.RT_ERR_NOT_INITIALIZED
+
+
+def test_argument_checks_before_any_device_work():
+    lib = _abi.load()
+    sph = np.zeros(1, _abi.SPHERE_DTYPE)
+    out = np.zeros(64, np.uint8)
+    st = _abi.TileStats()
+    rq = _abi.default_request(width=8, height=8, divisions=1, spp=1)
+    call = lambda r, o=out, n=None: lib.rt_render_tile(0, C.byref(r), _abi.ptr(sph), 1, None, 0, _abi.ptr(o),
+                                                       o.size if n is None else n, None, C.byref(st))
+    bad = rq.copy(); bad.division_no = 1
+    assert call(bad) == _abi.RT_ERR_BAD_ARG
+    bad = rq.copy(); bad.spp = 0
+    assert call(bad) == _abi.RT_ERR_BAD_ARG
+    bad = rq.copy(); bad.max_bounces = _abi.RT_MAX_BOUNCES + 1
+    assert call(bad) == _abi.RT_ERR_LIMIT
+    bad = rq.copy(); bad.reserved = 1
+    assert call(bad) == _abi.RT_ERR_BAD_ARG
+    assert call(rq) == _abi.RT_ERR_BUFFER_TOO_SMALL                   # 64 < 8*8*3
+    assert lib.rt_render_tile(0, None, None, 0, None, 0, None, 0, None, None) == _abi.RT_ERR_BAD_ARG
+    assert lib.rt_tile_bytes(None) == 0
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = ROOT / "ray_tracer_s8_amd"
+    for f in list(pkg.rglob("*.py")) + list(pkg.rglob("*.hip")) + list(pkg.rglob("*.h")):
+        txt = f.read_text()
+        assert not re.search(r"^\s*(import|from)\s+oracle\b", txt, re.M), f
+        assert not re.search(r"#\s*include\s*[<\"][^>\"]*oracle", txt), f
+        assert "librt_oracle" not in txt and "rt_oracle_" not in txt, f

@@ -1,0 +1,24 @@
+"""The oracle against the committed golden vectors (tests/golden, made by make_golden.py)."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from _golden import load_all
+
+CASES = load_all()
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_oracle_matches_golden(oracle, case):
+    rgb, f32, info = oracle.render(case["req"], case["spheres"], case["triangles"], backend=0, want_f32=True)
+    assert hashlib.sha256(rgb.tobytes()).hexdigest() == case["sha256_rgb"]
+    assert hashlib.sha256(f32.tobytes()).hexdigest() == case["sha256_f32"]
+    assert info["ray_segments"] == case["ray_segments"]
+    if case["rgb"] is not None:
+        assert np.array_equal(rgb, case["rgb"])
+
+
+def test_golden_set_is_present():
+    assert len(CASES) >= 6
+    assert any(c["triangles"] is not None for c in CASES)

@@ -43,6 +43,25 @@ def _compare(oracle, rq, sph, tri=None, backend=0, flags=0):
     return st
 
 
+from _golden import load_all as _load_golden
+import hashlib
+
+_GOLDEN = _load_golden()
+
+
+@pytest.mark.parametrize("case", _GOLDEN, ids=[c["name"] for c in _GOLDEN])
+def test_gpu_matches_committed_golden(ndev, case):
+    """HIP path vs the committed fixture bytes (no oracle call involved)."""
+    with rt.Scene(0, rt.World(case["spheres"], case["triangles"])) as sc:
+        rgb, f32, st = sc.render_tile(case["req"], want_f32=True)
+    assert hashlib.sha256(rgb.tobytes()).hexdigest() == case["sha256_rgb"]
+    assert hashlib.sha256(f32.tobytes()).hexdigest() == case["sha256_f32"]
+    assert st.ray_segments == case["ray_segments"]
+    if case["rgb"] is not None:
+        assert np.array_equal(rgb, case["rgb"])
+        assert rgb.std() > 1.0
+
+
 def test_c1_single_sphere(ndev, oracle):
     sph, rq = scenes.config("c1")
     _compare(oracle, rq, sph)
