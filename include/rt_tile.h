@@ -82,7 +82,12 @@ enum {
     /* Disable the conservative broad-phase filter: run the reference's exact root
      * computation against every primitive (slow; used by tests to prove the filter
      * never changes a result). */
-    RT_FLAG_EXACT_SCAN = 1u << 0
+    RT_FLAG_EXACT_SCAN = 1u << 0,
+    /* Plain linear-scan semantics: do not apply the reference's BVH candidate culling
+     * (bvh_impl.rs:373-398) to accepted hits and break distance ties by primitive index.
+     * Default (flag clear) reproduces the reference: a hit counts only if BVH::traverse would
+     * have returned the primitive, ties go to the earlier DFS leaf. */
+    RT_FLAG_NO_BVH_CULL = 1u << 1
 };
 
 typedef struct rt_tile_request {

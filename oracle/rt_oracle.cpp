@@ -660,32 +660,31 @@ struct Job {
     uint32_t hs;
 };
 
-void render_rows(const Job& job, uint32_t row_begin, uint32_t row_end, uint8_t* out_rgb, float* out_f32,
+// pixels [x_begin, x_end) of strip row yl
+void render_span(const Job& job, uint32_t yl, uint32_t x_begin, uint32_t x_end, uint8_t* out_rgb, float* out_f32,
                  uint64_t* segs) {
     const rt_tile_request& rq = job.req;
     Ctx cx{&job.sc, 0};
     const uint32_t W = rq.width, H = rq.height;
-    for (uint32_t yl = row_begin; yl < row_end; yl++) {
-        uint32_t yg = job.hs * rq.division_no + yl;  // :66-68
-        for (uint32_t x = 0; x < W; x++) {
-            uint32_t yc = H - yg - 1;  // :71
-            Rng rng = seed_from_u64(pixel_seed(rq.seed, (uint64_t)yg * W + x));
-            Color pix{0.f, 0.f, 0.f};
-            for (uint32_t s = 0; s < rq.spp; s++) {
-                Ray r = camera_get_ray(job.cam, x, yc, rng);
-                pix = pix + ray_color(cx, r, rq.max_bounces + 1, rng);
-            }
-            float n = (float)rq.spp;
-            pix.r = std::sqrt(pix.r / n);
-            pix.g = std::sqrt(pix.g / n);
-            pix.b = std::sqrt(pix.b / n);
-            size_t o = ((size_t)yl * W + x) * 3;
-            color_as_slice(pix, out_rgb + o);
-            if (out_f32) {
-                out_f32[o] = pix.r;
-                out_f32[o + 1] = pix.g;
-                out_f32[o + 2] = pix.b;
-            }
+    uint32_t yg = job.hs * rq.division_no + yl;  // :66-68
+    for (uint32_t x = x_begin; x < x_end; x++) {
+        uint32_t yc = H - yg - 1;  // :71
+        Rng rng = seed_from_u64(pixel_seed(rq.seed, (uint64_t)yg * W + x));
+        Color pix{0.f, 0.f, 0.f};
+        for (uint32_t s = 0; s < rq.spp; s++) {
+            Ray r = camera_get_ray(job.cam, x, yc, rng);
+            pix = pix + ray_color(cx, r, rq.max_bounces + 1, rng);
+        }
+        float n = (float)rq.spp;
+        pix.r = std::sqrt(pix.r / n);
+        pix.g = std::sqrt(pix.g / n);
+        pix.b = std::sqrt(pix.b / n);
+        size_t o = ((size_t)yl * W + x) * 3;
+        color_as_slice(pix, out_rgb + o);
+        if (out_f32) {
+            out_f32[o] = pix.r;
+            out_f32[o + 1] = pix.g;
+            out_f32[o + 2] = pix.b;
         }
     }
     *segs = cx.segments;
@@ -743,16 +742,23 @@ __attribute__((visibility("default"))) int rt_oracle_render(const rt_tile_reques
     job.hs = rq->height / rq->divisions;
     int nt_ = nthreads > 0 ? nthreads : (int)std::thread::hardware_concurrency();
     if (nt_ < 1) nt_ = 1;
-    if ((uint32_t)nt_ > job.hs) nt_ = job.hs ? (int)job.hs : 1;
-    std::atomic<uint32_t> next_row{0};
+    // work unit = 64 consecutive pixels of a row (the reference's rayon unit is a whole row,
+    // main.rs:62-65; a finer unit only changes scheduling, every pixel owns its RNG stream)
+    const uint32_t SPAN = 64;
+    const uint32_t spans_per_row = (rq->width + SPAN - 1) / SPAN;
+    const uint64_t n_units = (uint64_t)spans_per_row * job.hs;
+    if ((uint64_t)nt_ > n_units) nt_ = n_units ? (int)n_units : 1;
+    std::atomic<uint64_t> next_unit{0};
     std::vector<uint64_t> segs(nt_, 0);
     auto workfn = [&](int tid) {
         uint64_t total = 0;
         for (;;) {
-            uint32_t row = next_row.fetch_add(1);
-            if (row >= job.hs) break;
+            uint64_t u = next_unit.fetch_add(1);
+            if (u >= n_units) break;
+            uint32_t row = (uint32_t)(u / spans_per_row), sx = (uint32_t)(u % spans_per_row) * SPAN;
+            uint32_t ex = sx + SPAN < rq->width ? sx + SPAN : rq->width;
             uint64_t s = 0;
-            render_rows(job, row, row + 1, out_rgb, out_f32, &s);
+            render_span(job, row, sx, ex, out_rgb, out_f32, &s);
             total += s;
         }
         segs[tid] = total;

@@ -3,13 +3,13 @@
 Product code: the HIP kernel + C-ABI (csrc/, include/rt_tile.h) and this thin host-side
 mirror of the reference's RenderInfo/ImageSlice surface.  Nothing here imports oracle/.
 """
-from ._abi import (RT_FLAG_EXACT_SCAN, RT_FLAG_NONE, SPHERE_DTYPE, TRIANGLE_DTYPE, RtError, TileRequest,
+from ._abi import (RT_FLAG_EXACT_SCAN, RT_FLAG_NO_BVH_CULL, RT_FLAG_NONE, SPHERE_DTYPE, TRIANGLE_DTYPE, RtError, TileRequest,
                    TileStats, default_request)
 from .interface import (Controller, ImageSlice, RenderInfo, RenderMeta, RenderSettings, Scene, Slave, World, init,
                         render_frame_native)
 
 __all__ = [
-    "RT_FLAG_EXACT_SCAN", "RT_FLAG_NONE", "SPHERE_DTYPE", "TRIANGLE_DTYPE", "RtError", "TileRequest", "TileStats",
+    "RT_FLAG_EXACT_SCAN", "RT_FLAG_NO_BVH_CULL", "RT_FLAG_NONE", "SPHERE_DTYPE", "TRIANGLE_DTYPE", "RtError", "TileRequest", "TileStats",
     "default_request", "Controller", "ImageSlice", "RenderInfo", "RenderMeta", "RenderSettings", "Scene", "Slave",
     "World", "init", "render_frame_native",
 ]

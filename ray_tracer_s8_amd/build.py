@@ -35,7 +35,7 @@ def _sources() -> list[Path]:
 
 
 def _deps() -> list[Path]:
-    return [CSRC / "rt_api.hip", CSRC / "rt_kernel.hip.h", ROOT / "include" / "rt_tile.h", Path(__file__)]
+    return [CSRC / "rt_api.hip", CSRC / "rt_kernel.hip.h", CSRC / "rt_bvh.h", ROOT / "include" / "rt_tile.h", Path(__file__)]
 
 
 def needs_build() -> bool:

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -15,6 +16,7 @@
 #include <thread>
 #include <vector>
 
+#include "rt_bvh.h"
 #include "rt_kernel.hip.h"
 #include "rt_tile.h"
 
@@ -61,6 +63,9 @@ struct rt_scene {
     float4* d_mat = nullptr;
     float* d_emis = nullptr;
     float* d_tri = nullptr;
+    float4* d_bvh = nullptr;       // rtbvh::FlatNode[]
+    uint32_t* d_leaf_of = nullptr;
+    float bvh_build_ms = 0.f;
     unsigned long long* d_counters = nullptr;   // [0..2] stats, [4 + slot] tile queues
     // staging for the host-buffer entry point (grown on demand)
     uint8_t* d_out = nullptr;
@@ -175,6 +180,8 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     p.mat = sc->d_mat;
     p.emis = sc->d_emis;
     p.tri = sc->d_tri;
+    p.bvh_nodes = sc->d_bvh;
+    p.leaf_of = sc->d_leaf_of;
     p.n_strips = n;
     p.tiles_x = (p.W + 7) / 8;
     p.tiles_per_strip = p.tiles_x * ((p.Hs + 7) / 8);
@@ -386,6 +393,29 @@ RT_API int rt_scene_create(int device, const rt_sphere* sp, uint32_t ns, const r
         mat[ns + i] = make_float4(tr[i].albedo_r, tr[i].albedo_g, tr[i].albedo_b, tr[i].roughness);
         emis[ns + i] = tr[i].emission;
     }
+    // the reference's candidate-filter BVH (slave main.rs:60), built once per scene instead of per strip
+    std::vector<rtbvh::Box> boxes(np);
+    for (uint32_t i = 0; i < ns; i++) {              // Sphere::aabb, sphere.rs:65-72
+        const float c[3] = {sp[i].cx, sp[i].cy, sp[i].cz};
+        for (int a = 0; a < 3; a++) {
+            boxes[i].lo[a] = c[a] - sp[i].radius;
+            boxes[i].hi[a] = c[a] + sp[i].radius;
+        }
+    }
+    for (uint32_t i = 0; i < nt; i++) {              // Triangle::aabb, mesh.rs:46-96 (min_by / max_by order a,c,b)
+        for (int a = 0; a < 3; a++) {
+            const float va = tr[i].a[a], vb = tr[i].b[a], vc = tr[i].c[a];
+            const float m1 = va > vc ? vc : va;      // min_by(a, c): a unless a > c
+            boxes[ns + i].lo[a] = m1 > vb ? vb : m1;
+            const float x1 = va > vc ? va : vc;      // max_by(a, c): c unless a > c
+            boxes[ns + i].hi[a] = x1 > vb ? x1 : vb;
+        }
+    }
+    auto tb0 = std::chrono::steady_clock::now();
+    rtbvh::FlatBVH bvh = rtbvh::build(boxes);
+    sc->bvh_build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - tb0).count();
+    if (bvh.nodes.empty()) bvh.nodes.push_back(rtbvh::FlatNode{{0, 0, 0}, 0xffffffffu, {0, 0, 0}, 0});
+    if (bvh.leaf_of.empty()) bvh.leaf_of.push_back(0);
     auto cleanup = [&](int code) {
         rt_scene_destroy(sc);
         return code;
@@ -408,6 +438,8 @@ RT_API int rt_scene_create(int device, const rt_sphere* sp, uint32_t ns, const r
     SC_CHK(hipMalloc(&sc->d_mat, mat.size() * sizeof(float4)));
     SC_CHK(hipMalloc(&sc->d_emis, emis.size() * sizeof(float)));
     SC_CHK(hipMalloc(&sc->d_tri, tri.size() * sizeof(float)));
+    SC_CHK(hipMalloc(&sc->d_bvh, bvh.nodes.size() * sizeof(rtbvh::FlatNode)));
+    SC_CHK(hipMalloc(&sc->d_leaf_of, bvh.leaf_of.size() * sizeof(uint32_t)));
     SC_CHK(hipMalloc(&sc->d_counters, COUNTER_WORDS * sizeof(unsigned long long)));
     SC_CHK(hipEventRecord(e0, ctx->stream));
     SC_CHK(hipMemcpyAsync(sc->d_geom, geom.data(), geom.size() * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
@@ -416,6 +448,10 @@ RT_API int rt_scene_create(int device, const rt_sphere* sp, uint32_t ns, const r
     SC_CHK(hipMemcpyAsync(sc->d_mat, mat.data(), mat.size() * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
     SC_CHK(hipMemcpyAsync(sc->d_emis, emis.data(), emis.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     SC_CHK(hipMemcpyAsync(sc->d_tri, tri.data(), tri.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    SC_CHK(hipMemcpyAsync(sc->d_bvh, bvh.nodes.data(), bvh.nodes.size() * sizeof(rtbvh::FlatNode), hipMemcpyHostToDevice,
+                          ctx->stream));
+    SC_CHK(hipMemcpyAsync(sc->d_leaf_of, bvh.leaf_of.data(), bvh.leaf_of.size() * sizeof(uint32_t),
+                          hipMemcpyHostToDevice, ctx->stream));
     SC_CHK(hipMemsetAsync(sc->d_counters, 0, COUNTER_WORDS * sizeof(unsigned long long), ctx->stream));
     SC_CHK(hipEventRecord(e1, ctx->stream));
     SC_CHK(hipEventSynchronize(e1));
@@ -444,6 +480,8 @@ RT_API void rt_scene_destroy(rt_scene* sc) {
     (void)hipFree(sc->d_mat);
     (void)hipFree(sc->d_emis);
     (void)hipFree(sc->d_tri);
+    (void)hipFree(sc->d_bvh);
+    (void)hipFree(sc->d_leaf_of);
     (void)hipFree(sc->d_counters);
     (void)hipFree(sc->d_out);
     (void)hipFree(sc->d_outf);

@@ -1,0 +1,184 @@
+// rt_bvh.h — host-side construction of the reference's candidate-filter BVH (product code).
+//
+// The reference slave never tests a primitive the `bvh` crate's traversal did not return
+// (ray-tracer-slave/src/main.rs:112-114): a primitive is a candidate only if the ray passes the
+// AABB test of every node on its root-to-leaf path (bvh_impl.rs:373-398, ray.rs:174-194).
+// At large distances the reference's sphere roots lose precision (sphere.rs:45 squares a length
+// of ~1e2 to find a radius of ~1e-1) and report hits for rays that miss the sphere's AABB;
+// the BVH silently drops those.  To be pixel-for-pixel with the reference the GPU kernel therefore
+// validates an accepted hit against that same chain of AABB tests, and breaks exact distance
+// ties by DFS leaf order like `min_by` over the traversal output (shapes/mod.rs:177-182).
+//
+// This file builds the tree with the crate's algorithm (bvh_impl.rs:229-364: centroid-bounds
+// largest axis, 6 buckets, SAH cost, f32 arithmetic throughout) and flattens it to what the
+// kernel needs: for every node its parent and the AABB its parent stores for it, and for every
+// primitive its leaf node.  Node indices are assigned in the crate's order (pre-order, left
+// first), so a leaf's node index is also its DFS rank.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <limits>
+#include <vector>
+
+namespace rtbvh {
+
+struct Box {
+    float lo[3], hi[3];
+};
+
+struct FlatNode {          // 32 bytes: two float4 on the device
+    float lo[3];
+    uint32_t parent;       // 0xffffffff for the root
+    float hi[3];
+    uint32_t pad;
+};
+
+struct FlatBVH {
+    std::vector<FlatNode> nodes;
+    std::vector<uint32_t> leaf_of;   // primitive index -> node index (= DFS rank)
+};
+
+inline Box empty_box() {
+    const float inf = std::numeric_limits<float>::infinity();
+    return Box{{inf, inf, inf}, {-inf, -inf, -inf}};
+}
+// aabb.rs:268-282 join / :357-372 grow use f32::min / f32::max (IEEE minNum/maxNum)
+inline Box join(const Box& a, const Box& b) {
+    Box r;
+    for (int i = 0; i < 3; i++) {
+        r.lo[i] = fminf(a.lo[i], b.lo[i]);
+        r.hi[i] = fmaxf(a.hi[i], b.hi[i]);
+    }
+    return r;
+}
+inline void center(const Box& b, float c[3]) {      // aabb.rs:458-484: min + (max - min) / 2
+    for (int i = 0; i < 3; i++) c[i] = b.lo[i] + ((b.hi[i] - b.lo[i]) / 2.0f);
+}
+inline float surface_area(const Box& b) {           // aabb.rs:525-528
+    const float sx = b.hi[0] - b.lo[0], sy = b.hi[1] - b.lo[1], sz = b.hi[2] - b.lo[2];
+    return 2.0f * (sx * sy + sx * sz + sy * sz);
+}
+inline int largest_axis(const Box& b) {             // aabb.rs:570-580
+    const float sx = b.hi[0] - b.lo[0], sy = b.hi[1] - b.lo[1], sz = b.hi[2] - b.lo[2];
+    if (sx > sy && sx > sz) return 0;
+    if (sy > sz) return 1;
+    return 2;
+}
+
+// Build over the primitives' AABBs (`Bounded::aabb`, sphere.rs:65-72 / mesh.rs:46-96).
+inline FlatBVH build(const std::vector<Box>& prim) {
+    FlatBVH out;
+    out.leaf_of.assign(prim.size(), 0);
+    if (prim.empty()) return out;                   // the reference recurses without bound here
+    struct Item {
+        std::vector<uint32_t> idx;
+        uint32_t parent;
+        Box as_seen_by_parent;
+    };
+    std::vector<Item> stack;
+    {
+        Item root;
+        root.idx.resize(prim.size());
+        for (size_t i = 0; i < prim.size(); i++) root.idx[i] = (uint32_t)i;
+        root.parent = 0xffffffffu;
+        root.as_seen_by_parent = empty_box();
+        stack.push_back(std::move(root));
+    }
+    out.nodes.reserve(prim.size() * 2);
+    const float EPS = 0.00001f;                     // bvh lib.rs:80
+    while (!stack.empty()) {
+        Item it = std::move(stack.back());
+        stack.pop_back();
+        const uint32_t me = (uint32_t)out.nodes.size();
+        FlatNode fn;
+        for (int i = 0; i < 3; i++) {
+            fn.lo[i] = it.as_seen_by_parent.lo[i];
+            fn.hi[i] = it.as_seen_by_parent.hi[i];
+        }
+        fn.parent = it.parent;
+        fn.pad = 0;
+        out.nodes.push_back(fn);
+        if (it.idx.size() == 1) {                   // bvh_impl.rs:254-265
+            out.leaf_of[it.idx[0]] = me;
+            continue;
+        }
+        // convex hull of the shapes and of their centroids (:247-251)
+        Box all = empty_box(), cen = empty_box();
+        for (uint32_t s : it.idx) {
+            float c[3];
+            center(prim[s], c);
+            all = join(all, prim[s]);
+            for (int i = 0; i < 3; i++) {
+                cen.lo[i] = fminf(cen.lo[i], c[i]);
+                cen.hi[i] = fmaxf(cen.hi[i], c[i]);
+            }
+        }
+        const int ax = largest_axis(cen);
+        const float extent = cen.hi[ax] - cen.lo[ax];
+        Item L, R;
+        L.parent = R.parent = me;
+        auto halve = [&]() {                        // :277-291
+            const size_t h = it.idx.size() / 2;
+            L.idx.assign(it.idx.begin(), it.idx.begin() + h);
+            R.idx.assign(it.idx.begin() + h, it.idx.end());
+            L.as_seen_by_parent = empty_box();
+            for (uint32_t s : L.idx) L.as_seen_by_parent = join(L.as_seen_by_parent, prim[s]);
+            R.as_seen_by_parent = empty_box();
+            for (uint32_t s : R.idx) R.as_seen_by_parent = join(R.as_seen_by_parent, prim[s]);
+        };
+        if (extent < EPS) {
+            halve();
+        } else {                                    // :293-349, six SAH buckets
+            constexpr int NB = 6;
+            size_t cnt[NB] = {0, 0, 0, 0, 0, 0};
+            Box bb[NB];
+            std::vector<uint32_t> members[NB];
+            for (int b = 0; b < NB; b++) bb[b] = empty_box();
+            for (uint32_t s : it.idx) {
+                float c[3];
+                center(prim[s], c);
+                const float rel = (c[ax] - cen.lo[ax]) / extent;
+                const float fb = rel * ((float)NB - 0.01f);
+                size_t b = 0;                       // Rust `as usize`: truncate, saturate, NaN -> 0
+                if (fb == fb && fb > 0.0f) b = fb >= 1.8e19f ? (size_t)-1 : (size_t)fb;
+                if (b >= (size_t)NB) b = NB - 1;    // (the crate would index out of bounds)
+                cnt[b]++;
+                bb[b] = join(bb[b], prim[s]);
+                members[b].push_back(s);
+            }
+            int best = 0;
+            float best_cost = std::numeric_limits<float>::infinity();
+            Box best_l = empty_box(), best_r = empty_box();
+            for (int i = 0; i < NB - 1; i++) {
+                size_t nl = 0, nr = 0;
+                Box l = empty_box(), r = empty_box();
+                for (int b = 0; b <= i; b++) {
+                    nl += cnt[b];
+                    l = join(l, bb[b]);
+                }
+                for (int b = i + 1; b < NB; b++) {
+                    nr += cnt[b];
+                    r = join(r, bb[b]);
+                }
+                const float cost = ((float)nl * surface_area(l) + (float)nr * surface_area(r)) / surface_area(all);
+                if (cost < best_cost) {
+                    best = i;
+                    best_cost = cost;
+                    best_l = l;
+                    best_r = r;
+                }
+            }
+            for (int b = 0; b <= best; b++) L.idx.insert(L.idx.end(), members[b].begin(), members[b].end());
+            for (int b = best + 1; b < NB; b++) R.idx.insert(R.idx.end(), members[b].begin(), members[b].end());
+            L.as_seen_by_parent = best_l;
+            R.as_seen_by_parent = best_r;
+            if (L.idx.empty() || R.idx.empty()) halve();   // unreachable for finite centroids
+        }
+        // left subtree is numbered first: push right, then left
+        stack.push_back(std::move(R));
+        stack.push_back(std::move(L));
+    }
+    return out;
+}
+
+}  // namespace rtbvh

@@ -68,6 +68,8 @@ struct KParams {
     const float4* mat;           // [n_sph+n_tri] (albedo r,g,b, roughness)
     const float* emis;           // [n_sph+n_tri]
     const float* tri;            // [n_tri*9] a,b,c
+    const float4* bvh_nodes;     // [2*n_nodes]: (lo.xyz, parent as bits) (hi.xyz, -) — rt_bvh.h FlatNode
+    const uint32_t* leaf_of;     // [n_sph+n_tri] primitive -> leaf node index (= DFS rank)
     unsigned long long* counters;// [0] segments [1] candidates [2] fallbacks
     unsigned long long* queue;   // tile queue head of this launch (zeroed on the stream before it)
     StripDesc strips[MAX_BATCH];
@@ -234,21 +236,77 @@ __device__ __forceinline__ bool exact_triangle(V3 o, V3 d, const float* __restri
     return (dist >= t_min) && (dist < t_max);
 }
 
-// closest-hit bookkeeping: min_by on |P - origin|, first minimum wins, NaN keeps the
-// running one (shapes/mod.rs:177-182)
+// bvh::ray::Ray cached values (ray.rs:133-143) needed by intersects_aabb
+struct RayAux {
+    V3 inv;          // 1 / direction
+    bool sx, sy, sz; // direction < 0
+};
+__device__ __forceinline__ RayAux ray_aux(V3 d) {
+    RayAux a;
+    a.inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    a.sx = d.x < 0.0f;
+    a.sy = d.y < 0.0f;
+    a.sz = d.z < 0.0f;
+    return a;
+}
+// ray.rs:81-112: min/max with `if x < y {x} else {y}` semantics (not IEEE minNum)
+__device__ __forceinline__ float rmin(float x, float y) { return x < y ? x : y; }
+__device__ __forceinline__ float rmax(float x, float y) { return x > y ? x : y; }
+// Ray::intersects_aabb (ray.rs:174-194)
+__device__ __forceinline__ bool intersects_aabb(V3 o, const RayAux& a, float4 lo, float4 hi) {
+    float ray_min = ((a.sx ? hi.x : lo.x) - o.x) * a.inv.x;
+    float ray_max = ((a.sx ? lo.x : hi.x) - o.x) * a.inv.x;
+    float y_min = ((a.sy ? hi.y : lo.y) - o.y) * a.inv.y;
+    float y_max = ((a.sy ? lo.y : hi.y) - o.y) * a.inv.y;
+    ray_min = rmax(ray_min, y_min);
+    ray_max = rmin(ray_max, y_max);
+    float z_min = ((a.sz ? hi.z : lo.z) - o.z) * a.inv.z;
+    float z_max = ((a.sz ? lo.z : hi.z) - o.z) * a.inv.z;
+    ray_min = rmax(ray_min, z_min);
+    ray_max = rmin(ray_max, z_max);
+    return rmax(ray_min, 0.0f) <= ray_max;
+}
+// Would BVH::traverse (bvh_impl.rs:373-398) have returned this primitive?  Every node on the
+// leaf's path to the root must pass the AABB test its parent stores for it.
+__device__ __forceinline__ bool bvh_reaches(const float4* __restrict__ nodes, uint32_t node, V3 o, const RayAux& a) {
+    for (;;) {
+        const float4 lo = nodes[2 * (size_t)node];
+        const uint32_t parent = __float_as_uint(lo.w);
+        if (parent == 0xffffffffu) return true;              // root: no test (N = 1: always a candidate)
+        const float4 hi = nodes[2 * (size_t)node + 1];
+        if (!intersects_aabb(o, a, lo, hi)) return false;
+        node = parent;
+    }
+}
+
+// closest-hit bookkeeping: min_by on |P - origin| over the traversal output; the FIRST minimum in
+// DFS leaf order wins, NaN keeps the running one (shapes/mod.rs:177-182)
 struct Hit {
     int idx;
     float dist;
     V3 p;
+    uint32_t rank;   // DFS rank (leaf node index) of idx
 };
-__device__ __forceinline__ void consider(Hit& h, int idx, V3 o, V3 d, float t) {
+template <bool BVH>
+__device__ __forceinline__ void consider(Hit& h, int idx, V3 o, V3 d, float t, const RayAux& a,
+                                         const float4* __restrict__ nodes, const uint32_t* __restrict__ leaf_of) {
     V3 p = o + t * d;                    // Ray::at (ray.rs:147-149)
     float dist = vlength(p - o);
-    if (h.idx < 0 || h.dist > dist) {
-        h.idx = idx;
-        h.dist = dist;
-        h.p = p;
+    const bool better = h.idx < 0 || h.dist > dist;
+    const bool tie = h.idx >= 0 && h.dist == dist;
+    if (!(better || tie)) return;
+    uint32_t rank = (uint32_t)idx;
+    if (BVH) {
+        rank = leaf_of[idx];
+        if (!better && rank > h.rank) return;                // equal distance: earlier DFS leaf wins
+        if (!bvh_reaches(nodes, rank, o, a)) return;         // the reference never saw this primitive
+    } else {
+        if (!better) return;                                 // index order: first minimum wins
     }
+    h.idx = idx;
+    h.dist = dist;
+    h.p = p;
+    h.rank = rank;
 }
 
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
@@ -290,6 +348,7 @@ __global__ __launch_bounds__(BLOCK) void rt_tile_kernel(const KParams p) {
     const V3 hor = mk(p.hor[0], p.hor[1], p.hor[2]);
     const V3 ver = mk(p.ver[0], p.ver[1], p.ver[2]);
     const bool exact_scan = (p.flags & 1u) != 0;
+    const bool use_bvh = (p.flags & 2u) == 0;       // RT_FLAG_NO_BVH_CULL clears the reference's AABB-chain validation
     const float KMf = 1.0f - 0x1p-17f;              // broad-phase margin
     const v2f NKM = {-KMf, -KMf};
 
@@ -385,6 +444,8 @@ __global__ __launch_bounds__(BLOCK) void rt_tile_kernel(const KParams p) {
         h.idx = -1;
         h.dist = 0.f;
         h.p = mk(0, 0, 0);
+        h.rank = 0;
+        const RayAux aux = ray_aux(d);
         const V3 td = 2.0f * d;                              // (2f32 * ray.direction), sphere.rs:44
         if (active) n_seg++;
 
@@ -446,7 +507,12 @@ __global__ __launch_bounds__(BLOCK) void rt_tile_kernel(const KParams p) {
                     const V3 cen = mk(lgeomf[fo], lgeomf[fo + 2], lgeomf[fo + 4]);
                     const float rr = lgeomf[fo + 6];
                     float t;
-                    if (exact_sphere(o, td, cen, rr, p.t_min, p.t_max, t)) consider(h, (int)(base + j), o, d, t);
+                    if (exact_sphere(o, td, cen, rr, p.t_min, p.t_max, t)) {
+                        if (use_bvh)
+                            consider<true>(h, (int)(base + j), o, d, t, aux, p.bvh_nodes, p.leaf_of);
+                        else
+                            consider<false>(h, (int)(base + j), o, d, t, aux, p.bvh_nodes, p.leaf_of);
+                    }
                 }
             }
         }
@@ -454,8 +520,12 @@ __global__ __launch_bounds__(BLOCK) void rt_tile_kernel(const KParams p) {
             // triangles: exact test against every triangle (after the spheres in index order)
             for (uint32_t j = 0; j < p.n_tri; j++) {
                 float t;
-                if (exact_triangle(o, d, p.tri + 9 * (size_t)j, p.t_min, p.t_max, t))
-                    consider(h, (int)(p.n_sph + j), o, d, t);
+                if (exact_triangle(o, d, p.tri + 9 * (size_t)j, p.t_min, p.t_max, t)) {
+                    if (use_bvh)
+                        consider<true>(h, (int)(p.n_sph + j), o, d, t, aux, p.bvh_nodes, p.leaf_of);
+                    else
+                        consider<false>(h, (int)(p.n_sph + j), o, d, t, aux, p.bvh_nodes, p.leaf_of);
+                }
             }
 
             // ================= shade (main.rs:114-145) =================

@@ -35,5 +35,7 @@ def load_all():
         out.append(dict(name=f.stem, req=rq, spheres=sph, triangles=tri,
                         rgb=z["rgb"] if "rgb" in z.files else None,
                         sha256_rgb=str(z["sha256_rgb"]), sha256_f32=str(z["sha256_f32"]),
-                        ray_segments=int(z["ray_segments"])))
+                        ray_segments=int(z["ray_segments"]),
+                        sha256_rgb_linear=str(z["sha256_rgb_linear"]), sha256_f32_linear=str(z["sha256_f32_linear"]),
+                        ray_segments_linear=int(z["ray_segments_linear"])))
     return out

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generate tests/golden/*.npz from the CPU oracle (linear back-end).
+"""Generate tests/golden/*.npz from the CPU oracle (BVH back-end = reference semantics, and linear).
 
 The reference (Rust) cannot run in this image, so these vectors are outputs of the
 line-traceable restatement, cross-checked by oracle/restate_np.py — they pin regressions of
@@ -47,10 +47,15 @@ def req_fields(rq):
 
 def main():
     for name, rq, sph, tri, store in cases():
-        rgb, f32, info = oracle.render(rq, sph, tri, backend=0, want_f32=True)
+        # reference semantics = BVH candidate filter (backend 1); plain linear scan (backend 0) also pinned
+        rgb, f32, info = oracle.render(rq, sph, tri, backend=1, want_f32=True)
+        lin, lin_f, info_l = oracle.render(rq, sph, tri, backend=0, want_f32=True)
         sha = hashlib.sha256(rgb.tobytes()).hexdigest()
         sha_f = hashlib.sha256(f32.tobytes()).hexdigest()
-        out = dict(request=np.array([tuple(req_fields(rq).values())],
+        out = dict(sha256_rgb_linear=np.array(hashlib.sha256(lin.tobytes()).hexdigest()),
+                   sha256_f32_linear=np.array(hashlib.sha256(lin_f.tobytes()).hexdigest()),
+                   ray_segments_linear=np.array(info_l["ray_segments"], dtype=np.uint64),
+                   request=np.array([tuple(req_fields(rq).values())],
                                     dtype=[(k, "f8" if isinstance(v, float) else "u8") for k, v in req_fields(rq).items()]),
                    sha256_rgb=np.array(sha), sha256_f32=np.array(sha_f), ray_segments=np.array(info["ray_segments"], dtype=np.uint64))
         if store:

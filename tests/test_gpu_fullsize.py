@@ -1,0 +1,121 @@
+"""Parity at BASELINE.json's full sizes.
+
+The GPU box has enough host threads (256) for the oracle to render the full c2/c3 frames with
+the LINEAR back-end in seconds, so c2 and c3 are compared bit for bit at full size.  c4/c5 use
+(i) a sample of strips against the oracle and (ii) size-independent properties: the conservative
+broad phase never changes a result (filter == exact scan), strips stitch to the whole frame,
+batched == unbatched, and a checksum of the per-strip checksums is reproducible."""
+import hashlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import ray_tracer_s8_amd as rt
+from ray_tracer_s8_amd import scenes
+
+TOL_MEAN_ABS = 1e-5      # BASELINE.json: mean per-channel |delta| <= 1e-5 vs CPU (we get 0)
+
+
+@pytest.fixture(scope="module")
+def ndev():
+    return rt.init()
+
+
+def _frame_gpu(sph, rq, want_f32=False, flags=0):
+    reqs = []
+    for k in range(rq.divisions):
+        r = rq.copy()
+        r.division_no, r.flags = k, flags
+        reqs.append(r)
+    with rt.Scene(0, rt.World(sph)) as sc:
+        outs, outf, st = sc.render_tiles(reqs, want_f32=want_f32)
+    return np.concatenate(outs), (np.concatenate(outf) if want_f32 else None), st
+
+
+def _frame_oracle(oracle, sph, rq, backend):
+    whole = rq.copy()
+    whole.divisions, whole.division_no = 1, 0
+    return oracle.render(whole, sph, backend=backend, want_f32=True)
+
+
+def test_c2_full_1080p_bit_exact(ndev, oracle):
+    sph, rq = scenes.config("c2")                      # 16 spheres, 1920x1080, 4 spp, depth 4, 20 strips
+    rgb, f32, st = _frame_gpu(sph, rq, want_f32=True)
+    ref, ref_f, info = _frame_oracle(oracle, sph, rq, backend=1)      # reference semantics (BVH-culled)
+    assert float(np.abs(f32.astype(np.float64) - ref_f).mean()) <= TOL_MEAN_ABS
+    assert np.array_equal(rgb, ref)
+    assert np.array_equal(f32.view(np.uint32), ref_f.view(np.uint32))
+    assert st.ray_segments == info["ray_segments"] and st.primary_rays == 1920 * 1080 * 4
+    lin, _, st_l = _frame_gpu(sph, rq, flags=rt.RT_FLAG_NO_BVH_CULL)
+    ref_l, _, info_l = _frame_oracle(oracle, sph, rq, backend=0)
+    assert np.array_equal(lin, ref_l) and st_l.ray_segments == info_l["ray_segments"]
+
+
+def test_c3_full_4k_bit_exact_and_filter_is_conservative(ndev, oracle):
+    sph, rq = scenes.config("c3")                      # 1024 spheres, 3840x2160, 8 spp, depth 8
+    rgb, f32, st = _frame_gpu(sph, rq, want_f32=True)
+    ref, ref_f, info = _frame_oracle(oracle, sph, rq, backend=1)     # reference semantics
+    assert float(np.abs(f32.astype(np.float64) - ref_f).mean()) <= TOL_MEAN_ABS
+    assert np.array_equal(rgb, ref)
+    assert np.array_equal(f32.view(np.uint32), ref_f.view(np.uint32))
+    assert st.ray_segments == info["ray_segments"]
+    assert st.exact_fallbacks == 0
+    # property: broad phase off (exact root computation against every sphere) == broad phase on
+    rgb_x, _, st_x = _frame_gpu(sph, rq, flags=rt.RT_FLAG_EXACT_SCAN)
+    assert np.array_equal(rgb_x, rgb) and st_x.ray_segments == st.ray_segments
+    # plain linear-scan semantics against the oracle's linear back-end, also at full size
+    lin, _, st_l = _frame_gpu(sph, rq, flags=rt.RT_FLAG_NO_BVH_CULL)
+    ref_l, _, info_l = _frame_oracle(oracle, sph, rq, backend=0)
+    assert np.array_equal(lin, ref_l) and st_l.ray_segments == info_l["ray_segments"]
+
+
+def test_c4_8k_strip_sample_and_properties(ndev, oracle):
+    sph, rq = scenes.config("c4")                      # 7680x4320, 16 spp, 32 strips
+    picks = (0, 17, 31)
+    reqs = []
+    for k in picks:
+        r = rq.copy()
+        r.division_no = k
+        reqs.append(r)
+    with rt.Scene(0, rt.World(sph)) as sc:
+        outs, _, st = sc.render_tiles(reqs)                         # batched: one launch
+        single = sc.render_tile(reqs[1])[0]                         # unbatched
+    assert np.array_equal(single, outs[1])
+    segs = 0
+    for r, o in zip(reqs, outs):
+        ref, _, info = oracle.render(r, sph, backend=1)
+        assert np.array_equal(ref, o)
+        segs += info["ray_segments"]
+    assert st.ray_segments == segs
+
+
+def test_c5_65536_spheres_streamed_full_frame(ndev, oracle):
+    sph, rq = scenes.config("c5")                      # scene > LDS: streamed through LDS chunks
+    rgb, _, st = _frame_gpu(sph, rq)                    # the whole 4K frame, 16 strips, one launch
+    ref, _, info = _frame_oracle(oracle, sph, rq, backend=1)
+    assert np.array_equal(rgb, ref)
+    assert st.ray_segments == info["ray_segments"]
+    assert st.exact_fallbacks <= st.ray_segments // 1000
+    # plain linear semantics on a small frame against the LINEAR oracle
+    r2 = rq.copy()
+    r2.width, r2.height, r2.divisions, r2.division_no, r2.spp = 384, 216, 8, 5, 2
+    r2.flags = rt.RT_FLAG_NO_BVH_CULL
+    with rt.Scene(0, rt.World(sph)) as sc:
+        g, _, st3 = sc.render_tile(r2)
+    ref2, _, info2 = oracle.render(r2, sph, backend=0)
+    assert np.array_equal(g, ref2) and st3.ray_segments == info2["ray_segments"]
+
+
+def test_checksum_of_strip_checksums_is_reproducible(ndev):
+    sph, rq = scenes.config("c2")
+    digests = []
+    for _ in range(2):
+        rgb, _, _ = _frame_gpu(sph, rq)
+        strip = rgb.size // rq.divisions
+        h = hashlib.sha256()
+        for k in range(rq.divisions):
+            h.update(hashlib.sha256(rgb[k * strip:(k + 1) * strip].tobytes()).digest())
+        digests.append(h.hexdigest())
+    assert digests[0] == digests[1]

@@ -27,8 +27,11 @@ def _small(name, w, h, spp=None, div=1):
     return sph, rq
 
 
-def _compare(oracle, rq, sph, tri=None, backend=0, flags=0):
+def _compare(oracle, rq, sph, tri=None, flags=0):
+    """flags clear: reference semantics (BVH-culled candidates) vs the oracle's BVH back-end;
+    RT_FLAG_NO_BVH_CULL: plain linear scan vs the oracle's linear back-end."""
     rq = rq.copy()
+    backend = 0 if (flags & rt.RT_FLAG_NO_BVH_CULL) else 1
     ref_rgb, ref_f, info = oracle.render(rq, sph, tri, backend=backend, want_f32=True)
     rq.flags = flags
     with rt.Scene(0, rt.World(sph, tri)) as sc:
@@ -53,7 +56,13 @@ _GOLDEN = _load_golden()
 def test_gpu_matches_committed_golden(ndev, case):
     """HIP path vs the committed fixture bytes (no oracle call involved)."""
     with rt.Scene(0, rt.World(case["spheres"], case["triangles"])) as sc:
+        rl = case["req"].copy()
+        rl.flags = rt.RT_FLAG_NO_BVH_CULL
+        lin, lin_f, st_l = sc.render_tile(rl, want_f32=True)
         rgb, f32, st = sc.render_tile(case["req"], want_f32=True)
+    assert hashlib.sha256(lin.tobytes()).hexdigest() == case["sha256_rgb_linear"]
+    assert hashlib.sha256(lin_f.tobytes()).hexdigest() == case["sha256_f32_linear"]
+    assert st_l.ray_segments == case["ray_segments_linear"]
     assert hashlib.sha256(rgb.tobytes()).hexdigest() == case["sha256_rgb"]
     assert hashlib.sha256(f32.tobytes()).hexdigest() == case["sha256_f32"]
     assert st.ray_segments == case["ray_segments"]
@@ -84,6 +93,25 @@ def test_exact_scan_flag_equals_filter(ndev, oracle):
     b = _compare(oracle, rq, sph, flags=rt.RT_FLAG_EXACT_SCAN)
     assert a.ray_segments == b.ray_segments
     assert b.broad_candidates == 0
+
+
+@pytest.mark.parametrize("flags", [2, 3])
+def test_linear_scan_semantics_flag(ndev, oracle, flags):
+    # RT_FLAG_NO_BVH_CULL (with and without the broad phase) == the oracle's linear back-end
+    sph, rq = _small("c3", 240, 136, spp=2)
+    _compare(oracle, rq, sph, flags=flags)
+    sph, tri = scenes.quad_room()
+    rq = _abi.default_request(width=120, height=72, divisions=1, spp=2, max_bounces=5, seed=5)
+    _compare(oracle, rq, sph, tri, flags=flags)
+
+
+def test_far_false_hits_are_culled_like_the_reference(ndev, oracle):
+    """A distant small sphere: the reference's roots (sphere.rs:45) report a hit for rays that
+    miss the sphere's AABB; its BVH drops them.  Default flags must follow the BVH back-end."""
+    sph = scenes.rand65536(n=6000)
+    rq = _abi.default_request(width=256, height=144, divisions=1, spp=4, max_bounces=6, seed=1234)
+    _compare(oracle, rq, sph, flags=0)
+    _compare(oracle, rq, sph, flags=rt.RT_FLAG_NO_BVH_CULL)
 
 
 def test_ragged_sizes_and_strips(ndev, oracle):
@@ -154,7 +182,7 @@ def test_batched_strips_one_launch(ndev, oracle):
     assert st.n_launches == 1
     segs = 0
     for r, o, f in zip(reqs, outs, outf):
-        ref, ref_f, info = oracle.render(r, sph, want_f32=True)
+        ref, ref_f, info = oracle.render(r, sph, backend=1, want_f32=True)
         assert np.array_equal(o, ref)
         assert np.array_equal(f.view(np.uint32), ref_f.view(np.uint32))
         segs += info["ray_segments"]
