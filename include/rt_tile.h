@@ -87,7 +87,10 @@ enum {
      * (bvh_impl.rs:373-398) to accepted hits and break distance ties by primitive index.
      * Default (flag clear) reproduces the reference: a hit counts only if BVH::traverse would
      * have returned the primitive, ties go to the earlier DFS leaf. */
-    RT_FLAG_NO_BVH_CULL = 1u << 1
+    RT_FLAG_NO_BVH_CULL = 1u << 1,
+    /* Force the 11-op "oc" broad phase even when the scene qualifies for the 8-op expanded
+     * form (A/B testing; both are conservative and give identical images). */
+    RT_FLAG_OC_BROAD_PHASE = 1u << 2
 };
 
 typedef struct rt_tile_request {

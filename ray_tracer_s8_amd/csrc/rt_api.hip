@@ -60,6 +60,9 @@ struct rt_scene {
     uint32_t n_sph = 0, n_sph_pad = 0, n_tri = 0;
     float4* d_geom = nullptr;
     float4* d_geom_pk = nullptr;
+    float4* d_geom_px = nullptr;   // expanded-form broad phase records
+    float center[3] = {0.f, 0.f, 0.f};
+    bool expanded = false;         // host heuristic: expanded-form margin small against r^2
     float4* d_mat = nullptr;
     float* d_emis = nullptr;
     float* d_tri = nullptr;
@@ -176,6 +179,8 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     p.t_max = rq->t_max;
     p.spp_f = (float)rq->spp;
     p.geom_pk = sc->d_geom_pk;
+    p.geom_px = sc->d_geom_px;
+    for (int i = 0; i < 3; i++) p.center[i] = sc->center[i];
     p.geom = sc->d_geom;
     p.mat = sc->d_mat;
     p.emis = sc->d_emis;
@@ -201,10 +206,10 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
 
     // persistent grid: as many workgroups as the chip holds at this LDS/VGPR budget
     int per_cu = 0;
-    if (streamed)
-        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rtk::rt_tile_kernel<true>, rtk::BLOCK, lds));
-    else
-        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rtk::rt_tile_kernel<false>, rtk::BLOCK, lds));
+    const bool expanded = sc->expanded && !(rq->flags & RT_FLAG_OC_BROAD_PHASE);
+    void (*kern)(rtk::KParams) = streamed ? (expanded ? rtk::rt_tile_kernel<true, true> : rtk::rt_tile_kernel<true, false>)
+                                          : (expanded ? rtk::rt_tile_kernel<false, true> : rtk::rt_tile_kernel<false, false>);
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, rtk::BLOCK, lds));
     if (per_cu < 1) per_cu = 1;
     uint32_t blocks = (uint32_t)sc->ctx->n_cu * (uint32_t)per_cu;
     const uint32_t useful = (p.n_tiles + 3) / 4;                 // a wave needs at least one tile
@@ -215,10 +220,7 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     if (rc) return rc;
     HIPCHK(hipMemsetAsync(p.queue, 0, sizeof(unsigned long long), stream));
     HIPCHK(hipEventRecord(ev.a, stream));
-    if (streamed)
-        hipLaunchKernelGGL(rtk::rt_tile_kernel<true>, grid, block, lds, stream, p);
-    else
-        hipLaunchKernelGGL(rtk::rt_tile_kernel<false>, grid, block, lds, stream, p);
+    hipLaunchKernelGGL(kern, grid, block, lds, stream, p);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ev.b, stream));
     sc->pending.push_back({ev.a, ev.b});
@@ -330,9 +332,13 @@ RT_API int rt_init(int* n_devices) {
         c->dev = d;
         HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         HIPCHK(hipDeviceGetAttribute(&c->n_cu, hipDeviceAttributeMultiprocessorCount, d));
-        HIPCHK(hipFuncSetAttribute((const void*)rtk::rt_tile_kernel<false>,
+        HIPCHK(hipFuncSetAttribute((const void*)rtk::rt_tile_kernel<false, false>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
-        HIPCHK(hipFuncSetAttribute((const void*)rtk::rt_tile_kernel<true>,
+        HIPCHK(hipFuncSetAttribute((const void*)rtk::rt_tile_kernel<false, true>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
+        HIPCHK(hipFuncSetAttribute((const void*)rtk::rt_tile_kernel<true, false>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
+        HIPCHK(hipFuncSetAttribute((const void*)rtk::rt_tile_kernel<true, true>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
         g_ctx.push_back(c);
     }
@@ -393,6 +399,49 @@ RT_API int rt_scene_create(int device, const rt_sphere* sp, uint32_t ns, const r
         mat[ns + i] = make_float4(tr[i].albedo_r, tr[i].albedo_g, tr[i].albedo_b, tr[i].roughness);
         emis[ns + i] = tr[i].emission;
     }
+    // expanded-form broad phase records: coordinates relative to the scene centroid T,
+    // w = |c'|^2 - rr - 2^-16 (|c'|^2 + rr) evaluated in double and rounded DOWN to f32 (conservative).
+    std::vector<float4> geom_px(geom.size());
+    {
+        double T[3] = {0, 0, 0};
+        for (uint32_t i = 0; i < ns; i++) {
+            T[0] += sp[i].cx; T[1] += sp[i].cy; T[2] += sp[i].cz;
+        }
+        for (int a = 0; a < 3; a++) sc->center[a] = ns ? (float)(T[a] / ns) : 0.f;
+        std::vector<float4> px(geom.size());
+        std::vector<double> ratio;
+        const double K = std::ldexp(1.0, -16);
+        for (uint32_t i = 0; i < sc->n_sph_pad; i++) {
+            if (i >= ns) {
+                px[i] = make_float4(0.f, 0.f, 0.f, INFINITY);      // w = +inf: t = -inf, never a candidate
+                continue;
+            }
+            const float cpx = (float)((double)sp[i].cx - (double)sc->center[0]);
+            const float cpy = (float)((double)sp[i].cy - (double)sc->center[1]);
+            const float cpz = (float)((double)sp[i].cz - (double)sc->center[2]);
+            const double cc = (double)cpx * cpx + (double)cpy * cpy + (double)cpz * cpz;
+            const double rr = (double)geom[i].w;
+            const double w = cc - rr - K * (cc + rr);
+            float wf = (float)w;
+            if ((double)wf > w) wf = std::nextafterf(wf, -INFINITY);
+            px[i] = make_float4(cpx, cpy, cpz, wf);
+            if (rr > 0) ratio.push_back(K * 2.0 * cc / rr);
+        }
+        for (uint32_t i = 0; i + 1 < sc->n_sph_pad; i += 2) {
+            geom_px[i] = make_float4(px[i].x, px[i + 1].x, px[i].y, px[i + 1].y);
+            geom_px[i + 1] = make_float4(px[i].z, px[i + 1].z, px[i].w, px[i + 1].w);
+        }
+        // heuristic: the expanded form's additive margin 2^-16 (|o'|^2 + |c'|^2 + rr) must stay small against
+        // rr for the typical sphere, otherwise candidate lists blow up (c5-class scenes): then use the oc form.
+        bool ok = !ratio.empty();
+        if (ok) {
+            std::nth_element(ratio.begin(), ratio.begin() + ratio.size() / 2, ratio.end());
+            ok = ratio[ratio.size() / 2] < 0.25;
+        }
+        for (uint32_t i = 0; i < ns && ok; i++)
+            ok = std::isfinite(px[i].x) && std::isfinite(px[i].y) && std::isfinite(px[i].z) && std::isfinite(px[i].w);
+        sc->expanded = ok;
+    }
     // the reference's candidate-filter BVH (slave main.rs:60), built once per scene instead of per strip
     std::vector<rtbvh::Box> boxes(np);
     for (uint32_t i = 0; i < ns; i++) {              // Sphere::aabb, sphere.rs:65-72
@@ -435,6 +484,7 @@ RT_API int rt_scene_create(int device, const rt_sphere* sp, uint32_t ns, const r
     } while (0)
     SC_CHK(hipMalloc(&sc->d_geom, geom.size() * sizeof(float4)));
     SC_CHK(hipMalloc(&sc->d_geom_pk, geom_pk.size() * sizeof(float4)));
+    SC_CHK(hipMalloc(&sc->d_geom_px, geom_px.size() * sizeof(float4)));
     SC_CHK(hipMalloc(&sc->d_mat, mat.size() * sizeof(float4)));
     SC_CHK(hipMalloc(&sc->d_emis, emis.size() * sizeof(float)));
     SC_CHK(hipMalloc(&sc->d_tri, tri.size() * sizeof(float)));
@@ -444,6 +494,8 @@ RT_API int rt_scene_create(int device, const rt_sphere* sp, uint32_t ns, const r
     SC_CHK(hipEventRecord(e0, ctx->stream));
     SC_CHK(hipMemcpyAsync(sc->d_geom, geom.data(), geom.size() * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
     SC_CHK(hipMemcpyAsync(sc->d_geom_pk, geom_pk.data(), geom_pk.size() * sizeof(float4), hipMemcpyHostToDevice,
+                          ctx->stream));
+    SC_CHK(hipMemcpyAsync(sc->d_geom_px, geom_px.data(), geom_px.size() * sizeof(float4), hipMemcpyHostToDevice,
                           ctx->stream));
     SC_CHK(hipMemcpyAsync(sc->d_mat, mat.data(), mat.size() * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
     SC_CHK(hipMemcpyAsync(sc->d_emis, emis.data(), emis.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
@@ -477,6 +529,7 @@ RT_API void rt_scene_destroy(rt_scene* sc) {
     }
     (void)hipFree(sc->d_geom);
     (void)hipFree(sc->d_geom_pk);
+    (void)hipFree(sc->d_geom_px);
     (void)hipFree(sc->d_mat);
     (void)hipFree(sc->d_emis);
     (void)hipFree(sc->d_tri);

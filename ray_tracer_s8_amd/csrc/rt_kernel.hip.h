@@ -63,7 +63,10 @@ struct KParams {
     float u_den, v_den;          // aspect*H_f - 1, H_f - 1 (camera.rs:115-117)
     float t_min, t_max;
     float spp_f;
+    float center[3];             // scene centroid T (expanded broad phase works in o - T, c - T)
     const float4* geom_pk;       // [n_sph_pad/2][2]: (c0x,c1x,c0y,c1y) (c0z,c1z,rr0,rr1)
+    const float4* geom_px;       // expanded form: (c0x',c1x',c0y',c1y') (c0z',c1z',w0,w1), c' = c - T,
+                                 //   w = |c'|^2 - rr - 2^-16 (|c'|^2 + rr)
     const float4* geom;          // [n_sph_pad] (cx,cy,cz, RN(r*r))
     const float4* mat;           // [n_sph+n_tri] (albedo r,g,b, roughness)
     const float* emis;           // [n_sph+n_tri]
@@ -326,11 +329,11 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 
 // ------------------------------------------------------------------ the kernel
-template <bool STREAMED>
+template <bool STREAMED, bool EXPANDED>
 __global__ __launch_bounds__(BLOCK) void rt_tile_kernel(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    float4* lgeom = reinterpret_cast<float4*>(lds_raw);          // pair layout, see KParams::geom_pk
-    const float* lgeomf = reinterpret_cast<const float*>(lds_raw);
+    float4* lgeom = reinterpret_cast<float4*>(lds_raw);          // pair layout, see KParams::geom_pk / geom_px
+    const float4* __restrict__ gsrc = EXPANDED ? p.geom_px : p.geom_pk;
     uint16_t* lcand = reinterpret_cast<uint16_t*>(lds_raw + p.lds_cand_off);
     unsigned char* lpath = lds_raw + p.lds_path_off;
 
@@ -339,7 +342,7 @@ __global__ __launch_bounds__(BLOCK) void rt_tile_kernel(const KParams p) {
 
     if (!STREAMED) {
         // resident scene: stage the whole primitive list into LDS once
-        for (uint32_t i = tid; i < p.n_sph_pad; i += BLOCK) lgeom[i] = p.geom_pk[i];
+        for (uint32_t i = tid; i < p.n_sph_pad; i += BLOCK) lgeom[i] = gsrc[i];
         __syncthreads();
     }
 
@@ -454,28 +457,54 @@ __global__ __launch_bounds__(BLOCK) void rt_tile_kernel(const KParams p) {
             const uint32_t cn = min(p.chunk, p.n_sph_pad - base);   // multiple of UNROLL
             if (STREAMED) {
                 __syncthreads();
-                for (uint32_t i = tid; i < cn; i += BLOCK) lgeom[i] = p.geom_pk[base + i];
+                for (uint32_t i = tid; i < cn; i += BLOCK) lgeom[i] = gsrc[base + i];
                 __syncthreads();
             }
             if (active) {
                 uint32_t cnt = 0;
                 if (!exact_scan) {
                     // ---- broad phase: conservative "line misses sphere" rejection on sphere pairs.
-                    // t = b'^2 + rr - L2*(1-2^-17), b' = d.oc, L2 = |oc|^2 (FMA allowed: the value
-                    // only selects candidates, the narrow phase decides).  pass = !(t < 0).
-                    const v2f ox2 = {o.x, o.x}, oy2 = {o.y, o.y}, oz2 = {o.z, o.z};
-                    const v2f dx2 = {d.x, d.x}, dy2 = {d.y, d.y}, dz2 = {d.z, d.z};
+                    // The value only selects candidates (FMA allowed); the narrow phase decides.
+                    // pass = !(t < 0).  Two forms, chosen per scene by the host:
+                    //  oc form (11 packed ops / pair):  t = b'^2 + rr - L2 (1 - 2^-17),
+                    //          b' = d.(o-c), L2 = |o-c|^2
+                    //  expanded form (8 packed ops / pair), coordinates relative to the centroid T:
+                    //          t = (A - d.c')^2 - (oo'' + w - 2 o'.c'),  A = d.o', oo'' = |o'|^2 (1 - 2^-16),
+                    //          w = |c'|^2 - rr - 2^-16 (|c'|^2 + rr)  (host, rounded down)
+                    v2f k0x, k0y, k0z, k1x, k1y, k1z, kA, kB;
+                    if (EXPANDED) {
+                        const float opx = o.x - p.center[0], opy = o.y - p.center[1], opz = o.z - p.center[2];
+                        const float A = __builtin_fmaf(d.z, opz, __builtin_fmaf(d.y, opy, d.x * opx));
+                        const float oo = __builtin_fmaf(opz, opz, __builtin_fmaf(opy, opy, opx * opx)) * (1.0f - 0x1p-16f);
+                        k0x = v2f{-d.x, -d.x}; k0y = v2f{-d.y, -d.y}; k0z = v2f{-d.z, -d.z};
+                        k1x = v2f{-2.0f * opx, -2.0f * opx}; k1y = v2f{-2.0f * opy, -2.0f * opy};
+                        k1z = v2f{-2.0f * opz, -2.0f * opz};
+                        kA = v2f{A, A};
+                        kB = v2f{oo, oo};
+                    } else {
+                        k0x = v2f{o.x, o.x}; k0y = v2f{o.y, o.y}; k0z = v2f{o.z, o.z};
+                        k1x = v2f{d.x, d.x}; k1y = v2f{d.y, d.y}; k1z = v2f{d.z, d.z};
+                        kA = NKM;
+                        kB = NKM;
+                    }
                     for (uint32_t j = 0; j < cn; j += UNROLL) {
                         float t[UNROLL];
 #pragma unroll
                         for (int q = 0; q < UNROLL / 2; q++) {
-                            const float4 A = lgeom[j + 2 * q];
-                            const float4 B = lgeom[j + 2 * q + 1];
-                            const v2f cx = {A.x, A.y}, cy = {A.z, A.w}, cz = {B.x, B.y}, rr = {B.z, B.w};
-                            const v2f ocx = ox2 - cx, ocy = oy2 - cy, ocz = oz2 - cz;
-                            const v2f bb = pk_fma(dz2, ocz, pk_fma(dy2, ocy, dx2 * ocx));
-                            const v2f l2 = pk_fma(ocz, ocz, pk_fma(ocy, ocy, ocx * ocx));
-                            const v2f tt = pk_fma(l2, NKM, pk_fma(bb, bb, rr));
+                            const float4 A4 = lgeom[j + 2 * q];
+                            const float4 B4 = lgeom[j + 2 * q + 1];
+                            const v2f cx = {A4.x, A4.y}, cy = {A4.z, A4.w}, cz = {B4.x, B4.y}, cw = {B4.z, B4.w};
+                            v2f tt;
+                            if (EXPANDED) {
+                                const v2f bb = pk_fma(k0x, cx, pk_fma(k0y, cy, pk_fma(k0z, cz, kA)));
+                                const v2f qq = pk_fma(k1x, cx, pk_fma(k1y, cy, pk_fma(k1z, cz, cw + kB)));
+                                tt = pk_fma(bb, bb, -qq);
+                            } else {
+                                const v2f ocx = k0x - cx, ocy = k0y - cy, ocz = k0z - cz;
+                                const v2f bb = pk_fma(k1z, ocz, pk_fma(k1y, ocy, k1x * ocx));
+                                const v2f l2 = pk_fma(ocz, ocz, pk_fma(ocy, ocy, ocx * ocx));
+                                tt = pk_fma(l2, kA, pk_fma(bb, bb, cw));
+                            }
                             t[2 * q] = tt.x;
                             t[2 * q + 1] = tt.y;
                         }
@@ -503,11 +532,9 @@ __global__ __launch_bounds__(BLOCK) void rt_tile_kernel(const KParams p) {
                 const uint32_t n_it = direct ? cn : cnt;
                 for (uint32_t i = 0; i < n_it; i++) {
                     const uint32_t j = direct ? i : (uint32_t)lcand[i * BLOCK + tid];
-                    const uint32_t fo = (j >> 1) * 8 + (j & 1);
-                    const V3 cen = mk(lgeomf[fo], lgeomf[fo + 2], lgeomf[fo + 4]);
-                    const float rr = lgeomf[fo + 6];
+                    const float4 g = p.geom[base + j];                      // exact (cx,cy,cz, r^2)
                     float t;
-                    if (exact_sphere(o, td, cen, rr, p.t_min, p.t_max, t)) {
+                    if (exact_sphere(o, td, mk(g.x, g.y, g.z), g.w, p.t_min, p.t_max, t)) {
                         if (use_bvh)
                             consider<true>(h, (int)(base + j), o, d, t, aux, p.bvh_nodes, p.leaf_of);
                         else

@@ -65,6 +65,10 @@ def test_c3_full_4k_bit_exact_and_filter_is_conservative(ndev, oracle):
     # property: broad phase off (exact root computation against every sphere) == broad phase on
     rgb_x, _, st_x = _frame_gpu(sph, rq, flags=rt.RT_FLAG_EXACT_SCAN)
     assert np.array_equal(rgb_x, rgb) and st_x.ray_segments == st.ray_segments
+    # the two broad-phase forms (8-op expanded = default for this scene, 11-op oc) agree at full size
+    rgb_o, _, st_o = _frame_gpu(sph, rq, flags=4)
+    assert np.array_equal(rgb_o, rgb) and st_o.ray_segments == st.ray_segments
+    assert st.broad_candidates >= st_o.broad_candidates
     # plain linear-scan semantics against the oracle's linear back-end, also at full size
     lin, _, st_l = _frame_gpu(sph, rq, flags=rt.RT_FLAG_NO_BVH_CULL)
     ref_l, _, info_l = _frame_oracle(oracle, sph, rq, backend=0)

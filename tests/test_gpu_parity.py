@@ -105,6 +105,24 @@ def test_linear_scan_semantics_flag(ndev, oracle, flags):
     _compare(oracle, rq, sph, tri, flags=flags)
 
 
+def test_expanded_and_oc_broad_phase_agree(ndev, oracle):
+    # c3 qualifies for the 8-op expanded broad phase; RT_FLAG_OC_BROAD_PHASE forces the 11-op form.
+    # Both are conservative, so images and segment counts are identical; the expanded form's wider
+    # margin can only add candidates.
+    sph, rq = _small("c3", 320, 180, spp=4)
+    a = _compare(oracle, rq, sph, flags=0)
+    b = _compare(oracle, rq, sph, flags=_abi.RT_FLAG_OC_BROAD_PHASE)
+    assert a.ray_segments == b.ray_segments
+    assert a.broad_candidates >= b.broad_candidates > 0
+    # a scene far from its own centroid scale (large |c|^2 against r^2) must still be exact
+    far = sph.copy()
+    far["cx"] += 900.0
+    far["cz"] -= 700.0
+    rq2 = rq.copy()
+    rq2.width, rq2.height = 96, 54
+    _compare(oracle, rq2, far, flags=0)
+
+
 def test_far_false_hits_are_culled_like_the_reference(ndev, oracle):
     """A distant small sphere: the reference's roots (sphere.rs:45) report a hit for rays that
     miss the sphere's AABB; its BVH drops them.  Default flags must follow the BVH back-end."""
