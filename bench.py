@@ -44,6 +44,10 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scale", type=int, default=2, help="CPU baseline renders the frame at 1/scale resolution")
     ap.add_argument("--flags", type=int, default=0, help="rt_tile_request.flags (1 = exact scan)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for the barrier / timing reduce (gloo: rehearsal on one GPU)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="rehearsal only: all ranks use GPU 0 (a one-GPU box cannot run RCCL with 2 ranks)")
     return ap.parse_args()
 
 
@@ -94,13 +98,18 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    dev_index = 0 if args.share_device else local_rank
+    torch.cuda.set_device(dev_index)
+    red_dev = "cuda" if args.dist_backend == "nccl" else "cpu"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend="gloo")
 
     n_dev = rt.init()
-    assert local_rank < n_dev
+    assert dev_index < n_dev
     sph, rq0 = scenes.config(args.workload)
     rq0.flags = args.flags
     n_frames = world                                   # weak scaling: one frame of work per GPU
@@ -108,7 +117,7 @@ def main():
     strip_bytes = (rq0.height // rq0.divisions) * rq0.width * 3
     out = torch.empty(len(units) * strip_bytes, dtype=torch.uint8, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream   # kernels and torch.cuda.synchronize share it
-    scene = rt.Scene(local_rank, rt.World(sph))        # world resident in HBM before timing
+    scene = rt.Scene(dev_index, rt.World(sph))         # world resident in HBM before timing
 
     reqs = []
     for (f, d) in units:
@@ -152,10 +161,10 @@ def main():
     segs = float(st.ray_segments)
     prim = float(st.primary_rays)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        c = torch.tensor([segs, prim], dtype=torch.float64, device="cuda")
+        c = torch.tensor([segs, prim], dtype=torch.float64, device=red_dev)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         segs, prim = float(c[0].item()), float(c[1].item())
 

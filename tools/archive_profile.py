@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Copy the rocprofv3 summaries of gpurun_out/prof_<tag> into profiles/ (tracked) and derive
+profiles/hbm_traffic.json (HBM bytes per launch of the tile kernel, gfx950 corrections applied:
+FETCH_SIZE x2 for wide reads — MI355X_MICROARCH.md §HBM; units of both counters are KiB)."""
+import csv, glob, json, os, shutil, subprocess, sys
+tag, rnd, workload = sys.argv[1], sys.argv[2], (sys.argv[3] if len(sys.argv) > 3 else "c3")
+src = f"gpurun_out/prof_{tag}"
+os.makedirs("profiles", exist_ok=True)
+for f in glob.glob(f"{src}/trace/**/*kernel_stats.csv", recursive=True):
+    shutil.copy(f, f"profiles/{rnd}_{workload}_kernel_stats.csv")
+txt = subprocess.run([sys.executable, "tools/pmc_summary.py", src], capture_output=True, text=True).stdout
+open(f"profiles/{rnd}_{workload}_rocprof_summary.txt", "w").write(
+    f"# rocprofv3 --kernel-trace --stats and --pmc passes of: python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+    f" --workload {workload}\n# (separate passes per counter group; SQ_* cycle counters are quad-cycles)\n" + txt)
+def per_dispatch(name):
+    tot, n = 0.0, 0
+    for f in glob.glob(f"{src}/**/*counter_collection.csv", recursive=True):
+        for row in csv.DictReader(open(f)):
+            if row["Counter_Name"] == name and "rt_tile_kernel" in row["Kernel_Name"]:
+                tot += float(row["Counter_Value"]); n += 1
+    return tot / n if n else None
+fetch, write = per_dispatch("FETCH_SIZE"), per_dispatch("WRITE_SIZE")
+p = "profiles/hbm_traffic.json"
+d = json.load(open(p)) if os.path.exists(p) else {}
+if fetch is not None and write is not None:
+    d[workload] = {"bytes_per_launch": (2 * fetch + write) * 1024, "fetch_size_kib": fetch, "write_size_kib": write,
+                   "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B); "
+                           "WRITE_SIZE as reported (byte-granular RGB8 stores: uncalibrated width)", "round": rnd}
+json.dump(d, open(p, "w"), indent=1)
+print(open(f"profiles/{rnd}_{workload}_kernel_stats.csv").read())
+print(json.dumps(d, indent=1))
