@@ -61,7 +61,6 @@ struct rt_scene {
     float4* d_geom = nullptr;
     float4* d_geom_pk = nullptr;
     float4* d_geom_px = nullptr;   // expanded-form broad phase records
-    float center[3] = {0.f, 0.f, 0.f};
     bool expanded = false;         // host heuristic: expanded-form margin small against r^2
     float4* d_mat = nullptr;
     float* d_emis = nullptr;
@@ -172,7 +171,10 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     size_t cand_bytes = (size_t)rtk::MAXC * rtk::BLOCK * sizeof(uint16_t);
     p.lds_path_off = (uint32_t)(geom_bytes + cand_bytes);
     size_t path_bytes = (size_t)p.depth * rtk::BLOCK * (p.path32 ? 4 : 2);
-    size_t lds = geom_bytes + cand_bytes + path_bytes;
+    const bool expanded = sc->expanded && !(rq->flags & RT_FLAG_OC_BROAD_PHASE);
+    p.lds_rr_off = (uint32_t)(geom_bytes + cand_bytes + path_bytes);
+    size_t rr_bytes = expanded ? (size_t)(p.chunk ? p.chunk : 1) * sizeof(float) : 0;
+    size_t lds = geom_bytes + cand_bytes + path_bytes + rr_bytes;
     if (lds > LDS_LIMIT) return fail(RT_ERR_LIMIT, "LDS budget exceeded (scene chunk + path stack)");
     fill_camera(rq, p);
     p.t_min = rq->t_min;
@@ -180,7 +182,6 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     p.spp_f = (float)rq->spp;
     p.geom_pk = sc->d_geom_pk;
     p.geom_px = sc->d_geom_px;
-    for (int i = 0; i < 3; i++) p.center[i] = sc->center[i];
     p.geom = sc->d_geom;
     p.mat = sc->d_mat;
     p.emis = sc->d_emis;
@@ -206,7 +207,6 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
 
     // persistent grid: as many workgroups as the chip holds at this LDS/VGPR budget
     int per_cu = 0;
-    const bool expanded = sc->expanded && !(rq->flags & RT_FLAG_OC_BROAD_PHASE);
     void (*kern)(rtk::KParams) = streamed ? (expanded ? rtk::rt_tile_kernel<true, true> : rtk::rt_tile_kernel<true, false>)
                                           : (expanded ? rtk::rt_tile_kernel<false, true> : rtk::rt_tile_kernel<false, false>);
     HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, rtk::BLOCK, lds));
@@ -399,15 +399,10 @@ RT_API int rt_scene_create(int device, const rt_sphere* sp, uint32_t ns, const r
         mat[ns + i] = make_float4(tr[i].albedo_r, tr[i].albedo_g, tr[i].albedo_b, tr[i].roughness);
         emis[ns + i] = tr[i].emission;
     }
-    // expanded-form broad phase records: coordinates relative to the scene centroid T,
-    // w = |c'|^2 - rr - 2^-16 (|c'|^2 + rr) evaluated in double and rounded DOWN to f32 (conservative).
+    // expanded-form broad phase records: w = |c|^2 - rr - 2^-16 (|c|^2 + rr), evaluated in
+    // double and rounded DOWN to f32 (conservative).
     std::vector<float4> geom_px(geom.size());
     {
-        double T[3] = {0, 0, 0};
-        for (uint32_t i = 0; i < ns; i++) {
-            T[0] += sp[i].cx; T[1] += sp[i].cy; T[2] += sp[i].cz;
-        }
-        for (int a = 0; a < 3; a++) sc->center[a] = ns ? (float)(T[a] / ns) : 0.f;
         std::vector<float4> px(geom.size());
         std::vector<double> ratio;
         const double K = std::ldexp(1.0, -16);
@@ -416,27 +411,24 @@ RT_API int rt_scene_create(int device, const rt_sphere* sp, uint32_t ns, const r
                 px[i] = make_float4(0.f, 0.f, 0.f, INFINITY);      // w = +inf: t = -inf, never a candidate
                 continue;
             }
-            const float cpx = (float)((double)sp[i].cx - (double)sc->center[0]);
-            const float cpy = (float)((double)sp[i].cy - (double)sc->center[1]);
-            const float cpz = (float)((double)sp[i].cz - (double)sc->center[2]);
-            const double cc = (double)cpx * cpx + (double)cpy * cpy + (double)cpz * cpz;
+            const double cc = (double)sp[i].cx * sp[i].cx + (double)sp[i].cy * sp[i].cy + (double)sp[i].cz * sp[i].cz;
             const double rr = (double)geom[i].w;
             const double w = cc - rr - K * (cc + rr);
             float wf = (float)w;
             if ((double)wf > w) wf = std::nextafterf(wf, -INFINITY);
-            px[i] = make_float4(cpx, cpy, cpz, wf);
+            px[i] = make_float4(sp[i].cx, sp[i].cy, sp[i].cz, wf);
             if (rr > 0) ratio.push_back(K * 2.0 * cc / rr);
         }
         for (uint32_t i = 0; i + 1 < sc->n_sph_pad; i += 2) {
             geom_px[i] = make_float4(px[i].x, px[i + 1].x, px[i].y, px[i + 1].y);
             geom_px[i + 1] = make_float4(px[i].z, px[i + 1].z, px[i].w, px[i + 1].w);
         }
-        // heuristic: the expanded form's additive margin 2^-16 (|o'|^2 + |c'|^2 + rr) must stay small against
-        // rr for the typical sphere, otherwise candidate lists blow up (c5-class scenes): then use the oc form.
+        // heuristic: the expanded form's additive margin 2^-16 (|o|^2 + |c|^2 + rr) must stay small against rr
+        // for the typical sphere, otherwise candidate lists blow up (c5-class scenes): then use the oc form.
         bool ok = !ratio.empty();
         if (ok) {
             std::nth_element(ratio.begin(), ratio.begin() + ratio.size() / 2, ratio.end());
-            ok = ratio[ratio.size() / 2] < 0.25;
+            ok = ratio[ratio.size() / 2] < 0.5;
         }
         for (uint32_t i = 0; i < ns && ok; i++)
             ok = std::isfinite(px[i].x) && std::isfinite(px[i].y) && std::isfinite(px[i].z) && std::isfinite(px[i].w);

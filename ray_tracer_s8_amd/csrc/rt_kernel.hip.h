@@ -56,6 +56,7 @@ struct KParams {
     uint32_t path32;             // 1: path stack entries are u32, 0: u16
     uint32_t lds_cand_off;       // byte offsets into dynamic LDS
     uint32_t lds_path_off;
+    uint32_t lds_rr_off;
     uint32_t n_strips;           // strips in this launch
     uint32_t tiles_x, tiles_per_strip, n_tiles;   // 8x8 tiles
     float org[3], llc[3], hor[3], ver[3];   // Camera::new (camera.rs:19-47), host-computed
@@ -63,10 +64,9 @@ struct KParams {
     float u_den, v_den;          // aspect*H_f - 1, H_f - 1 (camera.rs:115-117)
     float t_min, t_max;
     float spp_f;
-    float center[3];             // scene centroid T (expanded broad phase works in o - T, c - T)
     const float4* geom_pk;       // [n_sph_pad/2][2]: (c0x,c1x,c0y,c1y) (c0z,c1z,rr0,rr1)
-    const float4* geom_px;       // expanded form: (c0x',c1x',c0y',c1y') (c0z',c1z',w0,w1), c' = c - T,
-                                 //   w = |c'|^2 - rr - 2^-16 (|c'|^2 + rr)
+    const float4* geom_px;       // expanded form: (c0x,c1x,c0y,c1y) (c0z,c1z,w0,w1),
+                                 //   w = |c|^2 - rr - 2^-16 (|c|^2 + rr)
     const float4* geom;          // [n_sph_pad] (cx,cy,cz, RN(r*r))
     const float4* mat;           // [n_sph+n_tri] (albedo r,g,b, roughness)
     const float* emis;           // [n_sph+n_tri]
@@ -288,9 +288,11 @@ struct Hit {
     int idx;
     float dist;
     V3 p;
-    uint32_t rank;   // DFS rank (leaf node index) of idx
 };
-template <bool BVH>
+// MODE 0: plain index order (RT_FLAG_NO_BVH_CULL).  MODE 1: BVH semantics, chain validation deferred
+// to the winner (ties still go to the earlier DFS leaf).  MODE 2: BVH semantics, every improving hit is
+// validated at once.
+template <int MODE>
 __device__ __forceinline__ void consider(Hit& h, int idx, V3 o, V3 d, float t, const RayAux& a,
                                          const float4* __restrict__ nodes, const uint32_t* __restrict__ leaf_of) {
     V3 p = o + t * d;                    // Ray::at (ray.rs:147-149)
@@ -298,18 +300,18 @@ __device__ __forceinline__ void consider(Hit& h, int idx, V3 o, V3 d, float t, c
     const bool better = h.idx < 0 || h.dist > dist;
     const bool tie = h.idx >= 0 && h.dist == dist;
     if (!(better || tie)) return;
-    uint32_t rank = (uint32_t)idx;
-    if (BVH) {
-        rank = leaf_of[idx];
-        if (!better && rank > h.rank) return;                // equal distance: earlier DFS leaf wins
-        if (!bvh_reaches(nodes, rank, o, a)) return;         // the reference never saw this primitive
-    } else {
+    if (MODE == 0) {
         if (!better) return;                                 // index order: first minimum wins
+    } else if (MODE == 1) {
+        if (!better && leaf_of[idx] > leaf_of[h.idx]) return;   // equal distance: earlier DFS leaf wins
+    } else {
+        const uint32_t rank = leaf_of[idx];
+        if (!better && rank > leaf_of[h.idx]) return;
+        if (!bvh_reaches(nodes, rank, o, a)) return;         // the reference never saw this primitive
     }
     h.idx = idx;
     h.dist = dist;
     h.p = p;
-    h.rank = rank;
 }
 
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
@@ -333,6 +335,8 @@ template <bool STREAMED, bool EXPANDED>
 __global__ __launch_bounds__(BLOCK) void rt_tile_kernel(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     float4* lgeom = reinterpret_cast<float4*>(lds_raw);          // pair layout, see KParams::geom_pk / geom_px
+    const float* lgeomf = reinterpret_cast<const float*>(lds_raw);
+    float* lrr = reinterpret_cast<float*>(lds_raw + p.lds_rr_off);   // EXPANDED: exact r^2 per sphere of the chunk
     const float4* __restrict__ gsrc = EXPANDED ? p.geom_px : p.geom_pk;
     uint16_t* lcand = reinterpret_cast<uint16_t*>(lds_raw + p.lds_cand_off);
     unsigned char* lpath = lds_raw + p.lds_path_off;
@@ -343,6 +347,8 @@ __global__ __launch_bounds__(BLOCK) void rt_tile_kernel(const KParams p) {
     if (!STREAMED) {
         // resident scene: stage the whole primitive list into LDS once
         for (uint32_t i = tid; i < p.n_sph_pad; i += BLOCK) lgeom[i] = gsrc[i];
+        if (EXPANDED)
+            for (uint32_t i = tid; i < p.n_sph_pad; i += BLOCK) lrr[i] = p.geom[i].w;
         __syncthreads();
     }
 
@@ -443,118 +449,145 @@ __global__ __launch_bounds__(BLOCK) void rt_tile_kernel(const KParams p) {
         }
 
         // ================= closest hit (shapes/mod.rs:158-191) =================
+        // Round 1 scans without the BVH chain and validates only the winner (an argmin of the
+        // root-test-pass set that is itself a BVH candidate is the argmin of the BVH candidates).
+        // If the winner is not a BVH candidate (the reference's false far hits, ~1e-5 of segments),
+        // round 2 rescans for that lane validating every improving hit.
         Hit h;
         h.idx = -1;
         h.dist = 0.f;
         h.p = mk(0, 0, 0);
-        h.rank = 0;
         const RayAux aux = ray_aux(d);
         const V3 td = 2.0f * d;                              // (2f32 * ray.direction), sphere.rs:44
         if (active) n_seg++;
-
-        for (uint32_t ch = 0; ch < p.n_chunks; ch++) {
-            const uint32_t base = ch * p.chunk;
-            const uint32_t cn = min(p.chunk, p.n_sph_pad - base);   // multiple of UNROLL
-            if (STREAMED) {
-                __syncthreads();
-                for (uint32_t i = tid; i < cn; i += BLOCK) lgeom[i] = gsrc[base + i];
-                __syncthreads();
-            }
-            if (active) {
-                uint32_t cnt = 0;
-                if (!exact_scan) {
-                    // ---- broad phase: conservative "line misses sphere" rejection on sphere pairs.
-                    // The value only selects candidates (FMA allowed); the narrow phase decides.
-                    // pass = !(t < 0).  Two forms, chosen per scene by the host:
-                    //  oc form (11 packed ops / pair):  t = b'^2 + rr - L2 (1 - 2^-17),
-                    //          b' = d.(o-c), L2 = |o-c|^2
-                    //  expanded form (8 packed ops / pair), coordinates relative to the centroid T:
-                    //          t = (A - d.c')^2 - (oo'' + w - 2 o'.c'),  A = d.o', oo'' = |o'|^2 (1 - 2^-16),
-                    //          w = |c'|^2 - rr - 2^-16 (|c'|^2 + rr)  (host, rounded down)
-                    v2f k0x, k0y, k0z, k1x, k1y, k1z, kA, kB;
-                    if (EXPANDED) {
-                        const float opx = o.x - p.center[0], opy = o.y - p.center[1], opz = o.z - p.center[2];
-                        const float A = __builtin_fmaf(d.z, opz, __builtin_fmaf(d.y, opy, d.x * opx));
-                        const float oo = __builtin_fmaf(opz, opz, __builtin_fmaf(opy, opy, opx * opx)) * (1.0f - 0x1p-16f);
-                        k0x = v2f{-d.x, -d.x}; k0y = v2f{-d.y, -d.y}; k0z = v2f{-d.z, -d.z};
-                        k1x = v2f{-2.0f * opx, -2.0f * opx}; k1y = v2f{-2.0f * opy, -2.0f * opy};
-                        k1z = v2f{-2.0f * opz, -2.0f * opz};
-                        kA = v2f{A, A};
-                        kB = v2f{oo, oo};
-                    } else {
-                        k0x = v2f{o.x, o.x}; k0y = v2f{o.y, o.y}; k0z = v2f{o.z, o.z};
-                        k1x = v2f{d.x, d.x}; k1y = v2f{d.y, d.y}; k1z = v2f{d.z, d.z};
-                        kA = NKM;
-                        kB = NKM;
-                    }
-                    for (uint32_t j = 0; j < cn; j += UNROLL) {
-                        float t[UNROLL];
-#pragma unroll
-                        for (int q = 0; q < UNROLL / 2; q++) {
-                            const float4 A4 = lgeom[j + 2 * q];
-                            const float4 B4 = lgeom[j + 2 * q + 1];
-                            const v2f cx = {A4.x, A4.y}, cy = {A4.z, A4.w}, cz = {B4.x, B4.y}, cw = {B4.z, B4.w};
-                            v2f tt;
-                            if (EXPANDED) {
-                                const v2f bb = pk_fma(k0x, cx, pk_fma(k0y, cy, pk_fma(k0z, cz, kA)));
-                                const v2f qq = pk_fma(k1x, cx, pk_fma(k1y, cy, pk_fma(k1z, cz, cw + kB)));
-                                tt = pk_fma(bb, bb, -qq);
-                            } else {
-                                const v2f ocx = k0x - cx, ocy = k0y - cy, ocz = k0z - cz;
-                                const v2f bb = pk_fma(k1z, ocz, pk_fma(k1y, ocy, k1x * ocx));
-                                const v2f l2 = pk_fma(ocz, ocz, pk_fma(ocy, ocy, ocx * ocx));
-                                tt = pk_fma(l2, kA, pk_fma(bb, bb, cw));
-                            }
-                            t[2 * q] = tt.x;
-                            t[2 * q + 1] = tt.y;
+        bool seg_active = active;
+        bool inline_chain = false;
+        for (;;) {
+            if (seg_active) h.idx = -1;
+            for (uint32_t ch = 0; ch < p.n_chunks; ch++) {
+                const uint32_t base = ch * p.chunk;
+                const uint32_t cn = min(p.chunk, p.n_sph_pad - base);   // multiple of UNROLL
+                if (STREAMED) {
+                    __syncthreads();
+                    for (uint32_t i = tid; i < cn; i += BLOCK) lgeom[i] = gsrc[base + i];
+                    if (EXPANDED)
+                        for (uint32_t i = tid; i < cn; i += BLOCK) lrr[i] = p.geom[base + i].w;
+                    __syncthreads();
+                }
+                if (seg_active) {
+                    uint32_t cnt = 0;
+                    if (!exact_scan) {
+                        // ---- broad phase: conservative "line misses sphere" rejection on sphere pairs.
+                        // The value only selects candidates (FMA allowed); the narrow phase decides.
+                        // pass = !(t < 0).  Two forms, chosen per scene by the host:
+                        //  oc form (11 packed ops / pair):  t = b'^2 + rr - L2 (1 - 2^-17),
+                        //          b' = d.(o-c), L2 = |o-c|^2
+                        //  expanded form (8 packed ops / pair):
+                        //          t = (A - d.c)^2 - (oo' + w - 2 o.c),  A = d.o, oo' = |o|^2 (1 - 2^-16),
+                        //          w = |c|^2 - rr - 2^-16 (|c|^2 + rr)  (host, rounded down)
+                        v2f k0x, k0y, k0z, k1x, k1y, k1z, kA, kB;
+                        if (EXPANDED) {
+                            const float A = __builtin_fmaf(d.z, o.z, __builtin_fmaf(d.y, o.y, d.x * o.x));
+                            const float oo =
+                                __builtin_fmaf(o.z, o.z, __builtin_fmaf(o.y, o.y, o.x * o.x)) * (1.0f - 0x1p-16f);
+                            k0x = v2f{-d.x, -d.x}; k0y = v2f{-d.y, -d.y}; k0z = v2f{-d.z, -d.z};
+                            k1x = v2f{-2.0f * o.x, -2.0f * o.x}; k1y = v2f{-2.0f * o.y, -2.0f * o.y};
+                            k1z = v2f{-2.0f * o.z, -2.0f * o.z};
+                            kA = v2f{A, A};
+                            kB = v2f{oo, oo};
+                        } else {
+                            k0x = v2f{o.x, o.x}; k0y = v2f{o.y, o.y}; k0z = v2f{o.z, o.z};
+                            k1x = v2f{d.x, d.x}; k1y = v2f{d.y, d.y}; k1z = v2f{d.z, d.z};
+                            kA = NKM;
+                            kB = NKM;
                         }
-                        // max ignores NaN; a NaN t can only come from non-finite operands, for
-                        // which the exact test reports a miss as well
-                        const float m = __builtin_fmaxf(
-                            __builtin_fmaxf(__builtin_fmaxf(t[0], t[1]), __builtin_fmaxf(t[2], t[3])),
-                            __builtin_fmaxf(__builtin_fmaxf(t[4], t[5]), __builtin_fmaxf(t[6], t[7])));
-                        if (!(m < 0.0f)) {
+                        for (uint32_t j = 0; j < cn; j += UNROLL) {
+                            float t[UNROLL];
 #pragma unroll
-                            for (int q = 0; q < UNROLL; q++) {
-                                if (!(t[q] < 0.0f)) {
-                                    if (cnt < (uint32_t)MAXC) lcand[cnt * BLOCK + tid] = (uint16_t)(j + q);
-                                    cnt++;
+                            for (int q = 0; q < UNROLL / 2; q++) {
+                                const float4 A4 = lgeom[j + 2 * q];
+                                const float4 B4 = lgeom[j + 2 * q + 1];
+                                const v2f cx = {A4.x, A4.y}, cy = {A4.z, A4.w}, cz = {B4.x, B4.y}, cw = {B4.z, B4.w};
+                                v2f tt;
+                                if (EXPANDED) {
+                                    const v2f bb = pk_fma(k0x, cx, pk_fma(k0y, cy, pk_fma(k0z, cz, kA)));
+                                    const v2f qq = pk_fma(k1x, cx, pk_fma(k1y, cy, pk_fma(k1z, cz, cw + kB)));
+                                    tt = pk_fma(bb, bb, -qq);
+                                } else {
+                                    const v2f ocx = k0x - cx, ocy = k0y - cy, ocz = k0z - cz;
+                                    const v2f bb = pk_fma(k1z, ocz, pk_fma(k1y, ocy, k1x * ocx));
+                                    const v2f l2 = pk_fma(ocz, ocz, pk_fma(ocy, ocy, ocx * ocx));
+                                    tt = pk_fma(l2, kA, pk_fma(bb, bb, cw));
+                                }
+                                t[2 * q] = tt.x;
+                                t[2 * q + 1] = tt.y;
+                            }
+                            // max ignores NaN; a NaN t can only come from non-finite operands, for
+                            // which the exact test reports a miss as well
+                            const float m = __builtin_fmaxf(
+                                __builtin_fmaxf(__builtin_fmaxf(t[0], t[1]), __builtin_fmaxf(t[2], t[3])),
+                                __builtin_fmaxf(__builtin_fmaxf(t[4], t[5]), __builtin_fmaxf(t[6], t[7])));
+                            if (!(m < 0.0f)) {
+#pragma unroll
+                                for (int q = 0; q < UNROLL; q++) {
+                                    if (!(t[q] < 0.0f)) {
+                                        if (cnt < (uint32_t)MAXC) lcand[cnt * BLOCK + tid] = (uint16_t)(j + q);
+                                        cnt++;
+                                    }
                                 }
                             }
                         }
+                        if (!inline_chain) n_cand += cnt;
                     }
-                    n_cand += cnt;
-                }
-                // ---- narrow phase: the reference's exact arithmetic, ascending index order.
-                // direct = every sphere of the chunk (exact-scan flag, or candidate list overflow)
-                const bool direct = exact_scan || cnt > (uint32_t)MAXC;
-                if (!exact_scan && direct) n_fall++;
-                const uint32_t n_it = direct ? cn : cnt;
-                for (uint32_t i = 0; i < n_it; i++) {
-                    const uint32_t j = direct ? i : (uint32_t)lcand[i * BLOCK + tid];
-                    const float4 g = p.geom[base + j];                      // exact (cx,cy,cz, r^2)
-                    float t;
-                    if (exact_sphere(o, td, mk(g.x, g.y, g.z), g.w, p.t_min, p.t_max, t)) {
-                        if (use_bvh)
-                            consider<true>(h, (int)(base + j), o, d, t, aux, p.bvh_nodes, p.leaf_of);
-                        else
-                            consider<false>(h, (int)(base + j), o, d, t, aux, p.bvh_nodes, p.leaf_of);
+                    // ---- narrow phase: the reference's exact arithmetic, ascending index order.
+                    // direct = every sphere of the chunk (exact-scan flag, or candidate list overflow)
+                    const bool direct = exact_scan || cnt > (uint32_t)MAXC;
+                    if (!exact_scan && direct && !inline_chain) n_fall++;
+                    const uint32_t n_it = direct ? cn : cnt;
+                    for (uint32_t i = 0; i < n_it; i++) {
+                        const uint32_t j = direct ? i : (uint32_t)lcand[i * BLOCK + tid];
+                        const uint32_t fo = (j >> 1) * 8 + (j & 1);                 // exact centre from the pair layout
+                        const V3 cen = mk(lgeomf[fo], lgeomf[fo + 2], lgeomf[fo + 4]);
+                        const float rr = EXPANDED ? lrr[j] : lgeomf[fo + 6];        // exact r^2
+                        float t;
+                        if (exact_sphere(o, td, cen, rr, p.t_min, p.t_max, t)) {
+                            if (!use_bvh)
+                                consider<0>(h, (int)(base + j), o, d, t, aux, p.bvh_nodes, p.leaf_of);
+                            else if (inline_chain)
+                                consider<2>(h, (int)(base + j), o, d, t, aux, p.bvh_nodes, p.leaf_of);
+                            else
+                                consider<1>(h, (int)(base + j), o, d, t, aux, p.bvh_nodes, p.leaf_of);
+                        }
                     }
                 }
             }
+            if (seg_active) {
+                // triangles: exact test against every triangle (after the spheres in index order)
+                for (uint32_t j = 0; j < p.n_tri; j++) {
+                    float t;
+                    if (exact_triangle(o, d, p.tri + 9 * (size_t)j, p.t_min, p.t_max, t)) {
+                        if (!use_bvh)
+                            consider<0>(h, (int)(p.n_sph + j), o, d, t, aux, p.bvh_nodes, p.leaf_of);
+                        else if (inline_chain)
+                            consider<2>(h, (int)(p.n_sph + j), o, d, t, aux, p.bvh_nodes, p.leaf_of);
+                        else
+                            consider<1>(h, (int)(p.n_sph + j), o, d, t, aux, p.bvh_nodes, p.leaf_of);
+                    }
+                }
+            }
+            // would BVH::traverse have returned the winner?  (root-to-leaf AABB chain)
+            bool redo = false;
+            if (seg_active && use_bvh && !inline_chain && h.idx >= 0)
+                redo = !bvh_reaches(p.bvh_nodes, p.leaf_of[h.idx], o, aux);
+            if (STREAMED) {
+                if (!__syncthreads_or(redo ? 1 : 0)) break;
+            } else {
+                if (!redo) break;
+            }
+            seg_active = redo;
+            inline_chain = true;
         }
         if (active) {
-            // triangles: exact test against every triangle (after the spheres in index order)
-            for (uint32_t j = 0; j < p.n_tri; j++) {
-                float t;
-                if (exact_triangle(o, d, p.tri + 9 * (size_t)j, p.t_min, p.t_max, t)) {
-                    if (use_bvh)
-                        consider<true>(h, (int)(p.n_sph + j), o, d, t, aux, p.bvh_nodes, p.leaf_of);
-                    else
-                        consider<false>(h, (int)(p.n_sph + j), o, d, t, aux, p.bvh_nodes, p.leaf_of);
-                }
-            }
-
             // ================= shade (main.rs:114-145) =================
             float term_r, term_g, term_b;
             bool finished;
