@@ -90,7 +90,10 @@ enum {
     RT_FLAG_NO_BVH_CULL = 1u << 1,
     /* Force the 11-op "oc" broad phase even when the scene qualifies for the 8-op expanded
      * form (A/B testing; both are conservative and give identical images). */
-    RT_FLAG_OC_BROAD_PHASE = 1u << 2
+    RT_FLAG_OC_BROAD_PHASE = 1u << 2,
+    /* Walk the whole root-to-leaf AABB chain when validating a hit instead of using the
+     * leaf-box monotonicity shortcut (A/B testing; identical images). */
+    RT_FLAG_FULL_CHAIN = 1u << 3
 };
 
 typedef struct rt_tile_request {

@@ -26,6 +26,7 @@ RT_FLAG_NONE = 0
 RT_FLAG_EXACT_SCAN = 1
 RT_FLAG_NO_BVH_CULL = 2
 RT_FLAG_OC_BROAD_PHASE = 4
+RT_FLAG_FULL_CHAIN = 8
 RT_MAX_BOUNCES = 62
 
 # numpy dtypes with the exact layout of rt_sphere / rt_triangle (no padding)

@@ -243,9 +243,11 @@ __device__ __forceinline__ bool exact_triangle(V3 o, V3 d, const float* __restri
 struct RayAux {
     V3 inv;          // 1 / direction
     bool sx, sy, sz; // direction < 0
+    bool full_chain; // RT_FLAG_FULL_CHAIN: never use the leaf-box shortcut (A/B testing)
 };
-__device__ __forceinline__ RayAux ray_aux(V3 d) {
+__device__ __forceinline__ RayAux ray_aux(V3 d, bool full_chain) {
     RayAux a;
+    a.full_chain = full_chain;
     a.inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     a.sx = d.x < 0.0f;
     a.sy = d.y < 0.0f;
@@ -271,13 +273,24 @@ __device__ __forceinline__ bool intersects_aabb(V3 o, const RayAux& a, float4 lo
 }
 // Would BVH::traverse (bvh_impl.rs:373-398) have returned this primitive?  Every node on the
 // leaf's path to the root must pass the AABB test its parent stores for it.
+//
+// Shortcut: every ancestor box contains the leaf's box exactly (f32 min/max joins do not round), and
+// with a FINITE inverse direction each step of intersects_aabb is monotone under IEEE rounding:
+// lo_a <= lo  =>  RN(lo_a - o) <= RN(lo - o)  =>  RN(.. * inv) ordered by the sign of inv, which is the
+// sign the slab selection uses; the custom min/max are monotone for non-NaN operands and no 0*inf can
+// occur.  Hence ray_min_a <= ray_min_leaf and ray_max_a >= ray_max_leaf: if the leaf's own box passes,
+// every ancestor passes.  Only when a direction component is +-0 (inv = +-inf) is the chain walked.
 __device__ __forceinline__ bool bvh_reaches(const float4* __restrict__ nodes, uint32_t node, V3 o, const RayAux& a) {
+    const float big = __builtin_inff();
+    const bool finite_inv = !a.full_chain && __builtin_fabsf(a.inv.x) < big && __builtin_fabsf(a.inv.y) < big &&
+                            __builtin_fabsf(a.inv.z) < big;
     for (;;) {
         const float4 lo = nodes[2 * (size_t)node];
         const uint32_t parent = __float_as_uint(lo.w);
         if (parent == 0xffffffffu) return true;              // root: no test (N = 1: always a candidate)
         const float4 hi = nodes[2 * (size_t)node + 1];
         if (!intersects_aabb(o, a, lo, hi)) return false;
+        if (finite_inv) return true;                         // leaf box passed => all ancestors pass
         node = parent;
     }
 }
@@ -457,7 +470,7 @@ __global__ __launch_bounds__(BLOCK) void rt_tile_kernel(const KParams p) {
         h.idx = -1;
         h.dist = 0.f;
         h.p = mk(0, 0, 0);
-        const RayAux aux = ray_aux(d);
+        const RayAux aux = ray_aux(d, (p.flags & 8u) != 0);
         const V3 td = 2.0f * d;                              // (2f32 * ray.direction), sphere.rs:44
         if (active) n_seg++;
         bool seg_active = active;

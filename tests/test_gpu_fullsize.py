@@ -102,6 +102,13 @@ def test_c5_65536_spheres_streamed_full_frame(ndev, oracle):
     assert np.array_equal(rgb, ref)
     assert st.ray_segments == info["ray_segments"]
     assert st.exact_fallbacks <= st.ray_segments // 1000
+    # leaf-box shortcut of the BVH validation == walking the whole chain (RT_FLAG_FULL_CHAIN)
+    r1 = rq.copy()
+    r1.division_no, r1.flags = 11, 8
+    with rt.Scene(0, rt.World(sph)) as sc:
+        full, _, st_f = sc.render_tile(r1)
+    strip = rgb.size // rq.divisions
+    assert np.array_equal(full, rgb[11 * strip:12 * strip])
     # plain linear semantics on a small frame against the LINEAR oracle
     r2 = rq.copy()
     r2.width, r2.height, r2.divisions, r2.division_no, r2.spp = 384, 216, 8, 5, 2

@@ -129,6 +129,7 @@ def test_far_false_hits_are_culled_like_the_reference(ndev, oracle):
     sph = scenes.rand65536(n=6000)
     rq = _abi.default_request(width=256, height=144, divisions=1, spp=4, max_bounces=6, seed=1234)
     _compare(oracle, rq, sph, flags=0)
+    _compare(oracle, rq, sph, flags=_abi.RT_FLAG_FULL_CHAIN)
     _compare(oracle, rq, sph, flags=rt.RT_FLAG_NO_BVH_CULL)
 
 
