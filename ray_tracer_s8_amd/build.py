@@ -51,7 +51,8 @@ def build(force: bool = False, verbose: bool = False) -> Path:
         return LIB_PATH
     LIB_DIR.mkdir(parents=True, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "hipcc")
-    cmd = [hipcc, *HIPCC_FLAGS, f"-I{ROOT / 'include'}", f"-I{CSRC}", "-o", str(LIB_PATH)]
+    extra = os.environ.get("RT_EXTRA_HIPCC_FLAGS", "").split()          # experiments only (e.g. -DRT_MAXC=12)
+    cmd = [hipcc, *HIPCC_FLAGS, *extra, f"-I{ROOT / 'include'}", f"-I{CSRC}", "-o", str(LIB_PATH)]
     cmd += [str(s) for s in _sources()]
     if verbose:
         print(" ".join(cmd))

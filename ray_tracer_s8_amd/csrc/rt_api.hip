@@ -655,6 +655,16 @@ RT_API int rt_scene_render_tile(rt_scene* sc, const rt_tile_request* rq, uint8_t
     return rt_scene_render_tiles(sc, rq, 1, rgb, out_len, out_f32 ? f32 : nullptr, stats);
 }
 
+// debug: raw read of the scene's device counter words (tools/phase_census.py); not part of rt_tile.h
+extern "C" __attribute__((visibility("default"))) int rt_debug_read_counters(rt_scene* sc, uint32_t first, uint32_t n,
+                                                                             unsigned long long* out) {
+    if (!sc || !out || first + n > COUNTER_WORDS) return RT_ERR_BAD_ARG;
+    if (hipSetDevice(sc->ctx->dev) != hipSuccess) return RT_ERR_HIP;
+    if (hipMemcpy(out, sc->d_counters + first, n * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess)
+        return RT_ERR_HIP;
+    return RT_OK;
+}
+
 RT_API int rt_render_tile(int device, const rt_tile_request* rq, const rt_sphere* sp, uint32_t ns,
                           const rt_triangle* tr, uint32_t nt, uint8_t* out_rgb, size_t out_len, float* out_f32,
                           rt_tile_stats* stats) {

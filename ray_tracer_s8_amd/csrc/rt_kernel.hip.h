@@ -32,8 +32,14 @@
 namespace rtk {
 
 constexpr int BLOCK = 256;       // 4 waves
-constexpr int MAXC = 16;         // candidate list slots per lane (per chunk)
-constexpr int CHUNK = 4096;      // max spheres per LDS chunk (64 KiB)
+#ifndef RT_MAXC
+#define RT_MAXC 16
+#endif
+#ifndef RT_MINWAVES
+#define RT_MINWAVES 1
+#endif
+constexpr int MAXC = RT_MAXC;    // candidate list slots per lane (per chunk)
+constexpr int CHUNK = 2048;      // max spheres per LDS chunk (32 KiB): list entries carry an 8-bit group index
 constexpr int UNROLL = 8;        // broad-phase unroll; chunk sizes are padded to this
 constexpr int MAX_BATCH = 64;    // strips per launch
 
@@ -340,12 +346,24 @@ __device__ __forceinline__ uint8_t f32_as_u8(float v) {
     return (uint8_t)(int)v;
 }
 
+// Phase census for tuning (compile with -DRT_PROFILE_PHASES; tools/phase_census.py): one count per wave
+// each time the code is reached by at least one lane.  Counters live in the spare queue slots [512..].
+#ifdef RT_PROFILE_PHASES
+#define WCOUNT(slot)                                                                         \
+    do {                                                                                     \
+        unsigned long long _m = __ballot(1);                                                 \
+        if ((int)(threadIdx.x & 63) == (int)__builtin_ctzll(_m)) atomicAdd(&p.counters[4 + 512 + (slot)], 1ull); \
+    } while (0)
+#else
+#define WCOUNT(slot) do { } while (0)
+#endif
+
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 
 // ------------------------------------------------------------------ the kernel
 template <bool STREAMED, bool EXPANDED>
-__global__ __launch_bounds__(BLOCK) void rt_tile_kernel(const KParams p) {
+__global__ __launch_bounds__(BLOCK, RT_MINWAVES) void rt_tile_kernel(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     float4* lgeom = reinterpret_cast<float4*>(lds_raw);          // pair layout, see KParams::geom_pk / geom_px
     const float* lgeomf = reinterpret_cast<const float*>(lds_raw);
@@ -375,7 +393,9 @@ __global__ __launch_bounds__(BLOCK) void rt_tile_kernel(const KParams p) {
     const v2f NKM = {-KMf, -KMf};
 
     // ---- wave-uniform tile cursor (kept identical in every live lane)
-    uint32_t tile_id = 0, tile_pos = 64;
+    uint32_t tile_pos = 64;
+    uint32_t tile_strip = 0, tile_x0 = 0, tile_y0 = 0, tile_yg0 = 0;   // decoded once per tile
+    uint64_t tile_seed = 0;
     // ---- per-lane pixel state
     bool have_pixel = false, retired = false, need_ray = false;
     uint32_t px = 0, pyl = 0, strip = 0;
@@ -388,6 +408,7 @@ __global__ __launch_bounds__(BLOCK) void rt_tile_kernel(const KParams p) {
     unsigned long long n_seg = 0, n_cand = 0, n_fall = 0;
 
     for (;;) {
+        WCOUNT(0);
         // ================= pixel acquisition: lanes pull pixels of the wave's current tile
         {
             bool need = !have_pixel && !retired;
@@ -403,7 +424,15 @@ __global__ __launch_bounds__(BLOCK) void rt_tile_kernel(const KParams p) {
                         if (need) retired = true;
                         break;
                     }
-                    tile_id = t;
+                    // decode the tile once, wave-uniformly: strip, tile origin, strip row offset and seed
+                    const uint32_t st = t / p.tiles_per_strip;
+                    const uint32_t rem = t - st * p.tiles_per_strip;
+                    const uint32_t ty = rem / p.tiles_x;
+                    tile_strip = st;
+                    tile_x0 = (rem - ty * p.tiles_x) * 8;
+                    tile_y0 = ty * 8;
+                    tile_yg0 = p.strips[st].y0;
+                    tile_seed = p.strips[st].seed;
                     tile_pos = 0;
                 }
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
@@ -411,19 +440,17 @@ __global__ __launch_bounds__(BLOCK) void rt_tile_kernel(const KParams p) {
                 const uint32_t avail = 64u - tile_pos;
                 const uint32_t want = (uint32_t)__builtin_popcountll(mask);
                 if (need && rank < avail) {
+                    WCOUNT(1);
                     const uint32_t pidx = tile_pos + rank;
-                    const uint32_t st = tile_id / p.tiles_per_strip;
-                    const uint32_t rem = tile_id - st * p.tiles_per_strip;
-                    const uint32_t ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
-                    const uint32_t x = tx * 8 + (pidx & 7), y = ty * 8 + (pidx >> 3);
+                    const uint32_t x = tile_x0 + (pidx & 7), y = tile_y0 + (pidx >> 3);
                     if (x < p.W && y < p.Hs) {
                         px = x;
                         pyl = y;
-                        strip = st;
-                        const uint32_t yg = p.strips[st].y0 + y;                  // main.rs:66-68
+                        strip = tile_strip;
+                        const uint32_t yg = tile_yg0 + y;                         // main.rs:66-68
                         xf = (float)x;
                         ycf = (float)(p.H - yg - 1);                              // main.rs:71
-                        rng = seed_pixel(p.strips[st].seed, (uint64_t)yg * p.W + x);
+                        rng = seed_pixel(tile_seed, (uint64_t)yg * p.W + x);
                         sum_r = sum_g = sum_b = 0.f;
                         s_idx = 0;
                         have_pixel = true;
@@ -438,7 +465,9 @@ __global__ __launch_bounds__(BLOCK) void rt_tile_kernel(const KParams p) {
         if (active && need_ray) {
             // ---- Camera::get_ray (camera.rs:109-129); RNG draw order is normative
             float a, bq;
+            WCOUNT(2);
             for (;;) {                                   // UnitDisc
+                WCOUNT(3);
                 a = uniform_m1_1(rng);
                 bq = uniform_m1_1(rng);
                 if (a * a + bq * bq <= 1.0f) break;
@@ -490,6 +519,7 @@ __global__ __launch_bounds__(BLOCK) void rt_tile_kernel(const KParams p) {
                 if (seg_active) {
                     uint32_t cnt = 0;
                     if (!exact_scan) {
+                        uint32_t ncand_it = 0;
                         // ---- broad phase: conservative "line misses sphere" rejection on sphere pairs.
                         // The value only selects candidates (FMA allowed); the narrow phase decides.
                         // pass = !(t < 0).  Two forms, chosen per scene by the host:
@@ -541,29 +571,49 @@ __global__ __launch_bounds__(BLOCK) void rt_tile_kernel(const KParams p) {
                                 __builtin_fmaxf(__builtin_fmaxf(t[0], t[1]), __builtin_fmaxf(t[2], t[3])),
                                 __builtin_fmaxf(__builtin_fmaxf(t[4], t[5]), __builtin_fmaxf(t[6], t[7])));
                             if (!(m < 0.0f)) {
+                                WCOUNT(4);
+                                // one list entry per passing group of 8: (group << 8) | pass mask.  The mask
+                                // comes from the sign bits (t >= +0 or NaN-with-clear-sign => candidate).
+                                uint32_t neg = 0;
 #pragma unroll
-                                for (int q = 0; q < UNROLL; q++) {
-                                    if (!(t[q] < 0.0f)) {
-                                        if (cnt < (uint32_t)MAXC) lcand[cnt * BLOCK + tid] = (uint16_t)(j + q);
-                                        cnt++;
-                                    }
-                                }
+                                for (int q = 0; q < UNROLL; q++) neg |= (__float_as_uint(t[q]) >> 31) << q;
+                                const uint32_t pass8 = ~neg & 0xffu;
+                                if (cnt < (uint32_t)MAXC) lcand[cnt * BLOCK + tid] = (uint16_t)(((j >> 3) << 8) | pass8);
+                                cnt++;
+                                ncand_it += (uint32_t)__builtin_popcount(pass8);
                             }
                         }
-                        if (!inline_chain) n_cand += cnt;
+                        if (!inline_chain) n_cand += ncand_it;
                     }
                     // ---- narrow phase: the reference's exact arithmetic, ascending index order.
                     // direct = every sphere of the chunk (exact-scan flag, or candidate list overflow)
                     const bool direct = exact_scan || cnt > (uint32_t)MAXC;
                     if (!exact_scan && direct && !inline_chain) n_fall++;
-                    const uint32_t n_it = direct ? cn : cnt;
-                    for (uint32_t i = 0; i < n_it; i++) {
-                        const uint32_t j = direct ? i : (uint32_t)lcand[i * BLOCK + tid];
+                    const uint32_t n_ent = direct ? (cn >> 3) : cnt;     // groups to visit
+                    uint32_t ei = 0, grp = 0, bits = 0;
+                    for (;;) {
+                        if (bits == 0) {                                  // next list entry / next group
+                            if (ei == n_ent) break;
+                            if (direct) {
+                                grp = ei;
+                                bits = 0xffu;
+                            } else {
+                                const uint32_t e = lcand[ei * BLOCK + tid];
+                                grp = e >> 8;
+                                bits = e & 0xffu;
+                            }
+                            ei++;
+                            if (bits == 0) continue;
+                        }
+                        WCOUNT(5);
+                        const uint32_t j = grp * 8 + (uint32_t)__builtin_ctz(bits);
+                        bits &= bits - 1;
                         const uint32_t fo = (j >> 1) * 8 + (j & 1);                 // exact centre from the pair layout
                         const V3 cen = mk(lgeomf[fo], lgeomf[fo + 2], lgeomf[fo + 4]);
                         const float rr = EXPANDED ? lrr[j] : lgeomf[fo + 6];        // exact r^2
                         float t;
                         if (exact_sphere(o, td, cen, rr, p.t_min, p.t_max, t)) {
+                            WCOUNT(6);
                             if (!use_bvh)
                                 consider<0>(h, (int)(base + j), o, d, t, aux, p.bvh_nodes, p.leaf_of);
                             else if (inline_chain)
@@ -590,8 +640,10 @@ __global__ __launch_bounds__(BLOCK) void rt_tile_kernel(const KParams p) {
             }
             // would BVH::traverse have returned the winner?  (root-to-leaf AABB chain)
             bool redo = false;
-            if (seg_active && use_bvh && !inline_chain && h.idx >= 0)
+            if (seg_active && use_bvh && !inline_chain && h.idx >= 0) {
+                WCOUNT(7);
                 redo = !bvh_reaches(p.bvh_nodes, p.leaf_of[h.idx], o, aux);
+            }
             if (STREAMED) {
                 if (!__syncthreads_or(redo ? 1 : 0)) break;
             } else {
@@ -605,6 +657,7 @@ __global__ __launch_bounds__(BLOCK) void rt_tile_kernel(const KParams p) {
             float term_r, term_g, term_b;
             bool finished;
             if (h.idx >= 0) {
+                WCOUNT(8);
                 const float em = p.emis[h.idx];
                 const float4 m = p.mat[h.idx];
                 if (em > 0.0f) {                              // main.rs:116-117
@@ -624,7 +677,9 @@ __global__ __launch_bounds__(BLOCK) void rt_tile_kernel(const KParams p) {
                     }
                     // UnitSphere (Marsaglia), main.rs:119
                     V3 us;
+                    WCOUNT(9);
                     for (;;) {
+                        WCOUNT(10);
                         float x1 = uniform_m1_1(rng);
                         float x2 = uniform_m1_1(rng);
                         float sm = x1 * x1 + x2 * x2;
@@ -651,6 +706,7 @@ __global__ __launch_bounds__(BLOCK) void rt_tile_kernel(const KParams p) {
                     term_r = term_g = term_b = 0.0f;
                 }
             } else {
+                WCOUNT(11);
                 // sky (main.rs:135-144)
                 float t = normalize_or_zero(d).y * 0.5f + 1.0f;
                 float omt = 1.0f - t;
@@ -660,8 +716,10 @@ __global__ __launch_bounds__(BLOCK) void rt_tile_kernel(const KParams p) {
                 finished = true;
             }
             if (finished) {
+                WCOUNT(12);
                 // a1 (.) (a2 (.) ( ... (ak (.) terminal))) : right-to-left (main.rs:123)
                 for (uint32_t i = k; i-- > 0;) {
+                    WCOUNT(13);
                     uint32_t idx = p.path32 ? reinterpret_cast<uint32_t*>(lpath)[i * BLOCK + tid]
                                             : (uint32_t) reinterpret_cast<uint16_t*>(lpath)[i * BLOCK + tid];
                     float4 m = p.mat[idx];
@@ -675,6 +733,7 @@ __global__ __launch_bounds__(BLOCK) void rt_tile_kernel(const KParams p) {
                 s_idx++;
                 need_ray = true;
                 if (s_idx == p.spp) {
+                    WCOUNT(14);
                     // ---- mean, gamma, quantise, store (main.rs:78-81)
                     float r = __builtin_sqrtf(sum_r / p.spp_f);
                     float g = __builtin_sqrtf(sum_g / p.spp_f);

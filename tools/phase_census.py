@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Phase census: build with -DRT_PROFILE_PHASES, render one c3 frame, print per-wave-iteration counts."""
+import ctypes as C, os, sys
+sys.path.insert(0, ".")
+os.environ["RT_EXTRA_HIPCC_FLAGS"] = "-DRT_PROFILE_PHASES"
+from ray_tracer_s8_amd import build
+build.build(force=True)
+import numpy as np, torch
+import ray_tracer_s8_amd as rt
+from ray_tracer_s8_amd import scenes, _abi
+rt.init()
+sph, rq = scenes.config(sys.argv[1] if len(sys.argv) > 1 else "c3")
+reqs = []
+for k in range(rq.divisions):
+    r = rq.copy(); r.division_no = k; reqs.append(r)
+names = ["main-loop iterations", "pixel acquisition body", "camera gen", "UnitDisc loop iters", "broad pass-branch entries",
+         "narrow loop iters", "exact hits -> consider", "bvh validation", "shade hit branch", "scatter (UnitSphere)",
+         "UnitSphere loop iters", "sky branch", "finish", "path product loop iters", "pixel finalize"]
+with rt.Scene(0, rt.World(sph)) as sc:
+    outs, _, st = sc.render_tiles(reqs)
+    lib = _abi.load()
+    # read raw counters through a tiny HIP memcpy via torch (device pointer is internal) -> use hip runtime
+    hip = C.CDLL("libamdhip64.so")
+    # counters pointer is not exported; re-render with stats only: use rt_debug_counters
+    buf = (C.c_ulonglong * 32)()
+    lib.rt_debug_read_counters.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+    lib.rt_debug_read_counters(sc._h, 4 + 512, 32, buf)
+    it = buf[0]
+    print(f"segments {st.ray_segments}  wave-iterations {it}  lanes/iter {st.ray_segments / it:.1f}")
+    for i, n in enumerate(names):
+        print(f"  [{i:2d}] {n:28s} {buf[i]:12d}   per iteration {buf[i] / it:7.3f}")
+os.environ["RT_EXTRA_HIPCC_FLAGS"] = ""
+build.build(force=True)
