@@ -1,0 +1,105 @@
+"""JSON wire codec of the reference's controller<->slave messages.
+
+serde_json forms (ray-tracer-slave/src/lib.rs:10-30, shapes/mod.rs:23-27, sphere.rs:12-20,
+mesh.rs:14-23, color.rs:5-10):
+  RenderInfo  {"world":[Object...], "render_meta":{"height","width","divisions","id"}, "division_no":n}
+  Object      externally tagged: {"Sphere":{"radius","center":[x,y,z],"node_index","p_albedo_at":{"r","g","b"},
+              "p_roughness_at","p_emission_at"}} | {"Triangle":{"a":[..],"b":[..],"c":[..],"node_index",
+              "p_albedo_at":{..},"p_roughness_at","p_emission_at"}}   (glam Vec3A serialises as [x,y,z])
+  ImageSlice  {"division_no":n, "image":[u8 as decimal numbers...], "id":"hyphenated-uuid"}
+f32 values travel as the shortest decimal of the f32 widened to f64 (serde_json `Value::from(f32)`), so the
+round trip is exact; that is what `float(np.float32(x))` + Python's repr produce as well.
+
+The reference `world` is one ordered list mixing both variants; the GPU ABI takes spheres then
+triangles, so decoding splits the list and keeps each variant's relative order.
+"""
+from __future__ import annotations
+
+import json
+import uuid
+from typing import Any
+
+import numpy as np
+
+from ._abi import SPHERE_DTYPE, TRIANGLE_DTYPE
+from .interface import ImageSlice, RenderInfo, RenderMeta, RenderSettings, World
+
+
+def _f(x) -> float:
+    return float(np.float32(x))
+
+
+def _color(rec) -> dict:
+    return {"r": _f(rec["albedo_r"]), "g": _f(rec["albedo_g"]), "b": _f(rec["albedo_b"])}
+
+
+def sphere_to_obj(s) -> dict:
+    return {"Sphere": {"radius": _f(s["radius"]), "center": [_f(s["cx"]), _f(s["cy"]), _f(s["cz"])], "node_index": 0,
+                       "p_albedo_at": _color(s), "p_roughness_at": _f(s["roughness"]),
+                       "p_emission_at": _f(s["emission"])}}
+
+
+def triangle_to_obj(t) -> dict:
+    return {"Triangle": {"a": [_f(v) for v in t["a"]], "b": [_f(v) for v in t["b"]], "c": [_f(v) for v in t["c"]],
+                         "node_index": 0, "p_albedo_at": _color(t), "p_roughness_at": _f(t["roughness"]),
+                         "p_emission_at": _f(t["emission"])}}
+
+
+def world_to_json_obj(world: World) -> list:
+    return [sphere_to_obj(s) for s in world.spheres] + [triangle_to_obj(t) for t in world.triangles]
+
+
+def world_from_json_obj(objs: list) -> World:
+    sph, tri = [], []
+    for o in objs:
+        if not isinstance(o, dict) or len(o) != 1:
+            raise ValueError("Object must be an externally tagged enum: {\"Sphere\":{..}} or {\"Triangle\":{..}}")
+        (tag, v), = o.items()
+        col = v["p_albedo_at"]
+        if tag == "Sphere":
+            c = v["center"]
+            sph.append((c[0], c[1], c[2], v["radius"], col["r"], col["g"], col["b"], v["p_roughness_at"],
+                        v["p_emission_at"]))
+        elif tag == "Triangle":
+            tri.append((tuple(v["a"]), tuple(v["b"]), tuple(v["c"]), col["r"], col["g"], col["b"],
+                        v["p_roughness_at"], v["p_emission_at"]))
+        else:
+            raise ValueError(f"unknown variant `{tag}`, expected `Sphere` or `Triangle`")
+    return World(np.array(sph, dtype=SPHERE_DTYPE) if sph else np.zeros(0, SPHERE_DTYPE),
+                 np.array(tri, dtype=TRIANGLE_DTYPE) if tri else np.zeros(0, TRIANGLE_DTYPE))
+
+
+def encode_render_info(info: RenderInfo) -> str:
+    """What the controller POSTs to a slave (controller main.rs:58-63)."""
+    m = info.render_meta
+    return json.dumps({"division_no": int(info.division_no),
+                       "render_meta": {"divisions": int(m.divisions), "height": int(m.height), "id": str(m.id),
+                                       "width": int(m.width)},
+                       "world": world_to_json_obj(info.world)}, separators=(",", ":"))
+
+
+def decode_render_info(text: str | bytes, settings: RenderSettings | None = None) -> RenderInfo:
+    """What the slave's `web::Json<RenderInfo>` extractor accepts (slave main.rs:148-152)."""
+    d = json.loads(text)
+    for k in ("world", "render_meta", "division_no"):
+        if k not in d:
+            raise ValueError(f"missing field `{k}`")
+    rm = d["render_meta"]
+    meta = RenderMeta(height=int(rm["height"]), width=int(rm["width"]), divisions=int(rm["divisions"]),
+                      id=uuid.UUID(rm["id"]))
+    return RenderInfo(world_from_json_obj(d["world"]), meta, int(d["division_no"]), settings or RenderSettings())
+
+
+def encode_image_slice(s: ImageSlice) -> str:
+    """What the slave POSTs to master:8080/result (slave main.rs:85-90): `image` is a JSON number array."""
+    img = np.asarray(s.image, dtype=np.uint8).reshape(-1)
+    body = ",".join(map(str, img.tolist()))
+    return '{"division_no":%d,"id":"%s","image":[%s]}' % (int(s.division_no), str(s.id), body)
+
+
+def decode_image_slice(text: str | bytes) -> ImageSlice:
+    d = json.loads(text)
+    img = np.asarray(d["image"], dtype=np.int64)
+    if img.size and (img.min() < 0 or img.max() > 255):
+        raise ValueError("image element out of range for u8")
+    return ImageSlice(division_no=int(d["division_no"]), image=img.astype(np.uint8), id=uuid.UUID(d["id"]))

@@ -234,3 +234,34 @@ def test_determinism_and_seed(ndev):
         c = sc.render_tile(rq)[0]
     assert np.array_equal(a, b)
     assert not np.array_equal(a, c)
+
+
+def test_http_slave_shim_on_gpu(ndev, oracle):
+    """POST RenderInfo JSON to the GPU slave shim, collect ImageSlice JSON at a fake master, assemble."""
+    import urllib.request
+    from _fakes import FakeMaster
+    from ray_tracer_s8_amd import dispatch, wire
+    from ray_tracer_s8_amd.interface import RenderInfo, RenderMeta, RenderSettings, World
+    from ray_tracer_s8_amd.slave_shim import REPLY, SlaveService
+    master = FakeMaster()
+    svc = SlaveService(device=0, master_url=f"http://127.0.0.1:{master.port}/result", host="127.0.0.1", port=0,
+                       settings=RenderSettings(spp=4, max_bounces=4), fixed_seed=1234).start()
+    try:
+        meta = RenderMeta(height=90, width=160, divisions=5)
+        world = World(scenes.cornell16())
+        for k in range(5):
+            body = wire.encode_render_info(RenderInfo(world, meta, k)).encode()
+            req = urllib.request.Request(f"http://127.0.0.1:{svc.port}/", data=body,
+                                         headers={"Content-Type": "application/json"}, method="POST")
+            with urllib.request.urlopen(req, timeout=60) as r:
+                assert r.read() == REPLY
+        svc.wait_idle()
+        slices = [wire.decode_image_slice(b) for _, _, b in master.got]
+        frame = dispatch.assemble([(s.division_no, s.image) for s in slices], 160, 90, 5)
+        rq = RenderInfo(world, meta, 0, RenderSettings(spp=4, max_bounces=4, seed=1234)).request()
+        rq.divisions = 1
+        ref, _, _ = oracle.render(rq, world.spheres, backend=1)
+        assert np.array_equal(frame.reshape(-1), ref)
+    finally:
+        svc.stop()
+        master.stop()
