@@ -65,6 +65,7 @@ struct rt_scene {
     float4* d_mat = nullptr;
     float* d_emis = nullptr;
     float* d_tri = nullptr;
+    float4* d_tri_box = nullptr;
     float4* d_bvh = nullptr;       // rtbvh::FlatNode[]
     uint32_t* d_leaf_of = nullptr;
     float bvh_build_ms = 0.f;
@@ -186,6 +187,7 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     p.mat = sc->d_mat;
     p.emis = sc->d_emis;
     p.tri = sc->d_tri;
+    p.tri_box = sc->d_tri_box;
     p.bvh_nodes = sc->d_bvh;
     p.leaf_of = sc->d_leaf_of;
     p.n_strips = n;
@@ -452,6 +454,12 @@ RT_API int rt_scene_create(int device, const rt_sphere* sp, uint32_t ns, const r
             boxes[ns + i].hi[a] = x1 > vb ? x1 : vb;
         }
     }
+    std::vector<float4> tri_box((size_t)nt * 2 + 1);
+    for (uint32_t i = 0; i < nt; i++) {
+        const rtbvh::Box& b = boxes[ns + i];
+        tri_box[2 * (size_t)i] = make_float4(b.lo[0], b.lo[1], b.lo[2], 0.f);
+        tri_box[2 * (size_t)i + 1] = make_float4(b.hi[0], b.hi[1], b.hi[2], 0.f);
+    }
     auto tb0 = std::chrono::steady_clock::now();
     rtbvh::FlatBVH bvh = rtbvh::build(boxes);
     sc->bvh_build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - tb0).count();
@@ -480,6 +488,7 @@ RT_API int rt_scene_create(int device, const rt_sphere* sp, uint32_t ns, const r
     SC_CHK(hipMalloc(&sc->d_mat, mat.size() * sizeof(float4)));
     SC_CHK(hipMalloc(&sc->d_emis, emis.size() * sizeof(float)));
     SC_CHK(hipMalloc(&sc->d_tri, tri.size() * sizeof(float)));
+    SC_CHK(hipMalloc(&sc->d_tri_box, tri_box.size() * sizeof(float4)));
     SC_CHK(hipMalloc(&sc->d_bvh, bvh.nodes.size() * sizeof(rtbvh::FlatNode)));
     SC_CHK(hipMalloc(&sc->d_leaf_of, bvh.leaf_of.size() * sizeof(uint32_t)));
     SC_CHK(hipMalloc(&sc->d_counters, COUNTER_WORDS * sizeof(unsigned long long)));
@@ -492,6 +501,8 @@ RT_API int rt_scene_create(int device, const rt_sphere* sp, uint32_t ns, const r
     SC_CHK(hipMemcpyAsync(sc->d_mat, mat.data(), mat.size() * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
     SC_CHK(hipMemcpyAsync(sc->d_emis, emis.data(), emis.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     SC_CHK(hipMemcpyAsync(sc->d_tri, tri.data(), tri.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    SC_CHK(hipMemcpyAsync(sc->d_tri_box, tri_box.data(), tri_box.size() * sizeof(float4), hipMemcpyHostToDevice,
+                          ctx->stream));
     SC_CHK(hipMemcpyAsync(sc->d_bvh, bvh.nodes.data(), bvh.nodes.size() * sizeof(rtbvh::FlatNode), hipMemcpyHostToDevice,
                           ctx->stream));
     SC_CHK(hipMemcpyAsync(sc->d_leaf_of, bvh.leaf_of.data(), bvh.leaf_of.size() * sizeof(uint32_t),
@@ -525,6 +536,7 @@ RT_API void rt_scene_destroy(rt_scene* sc) {
     (void)hipFree(sc->d_mat);
     (void)hipFree(sc->d_emis);
     (void)hipFree(sc->d_tri);
+    (void)hipFree(sc->d_tri_box);
     (void)hipFree(sc->d_bvh);
     (void)hipFree(sc->d_leaf_of);
     (void)hipFree(sc->d_counters);

@@ -77,6 +77,7 @@ struct KParams {
     const float4* mat;           // [n_sph+n_tri] (albedo r,g,b, roughness)
     const float* emis;           // [n_sph+n_tri]
     const float* tri;            // [n_tri*9] a,b,c
+    const float4* tri_box;       // [2*n_tri] Triangle::aabb (lo, hi) as the BVH sees it
     const float4* bvh_nodes;     // [2*n_nodes]: (lo.xyz, parent as bits) (hi.xyz, -) — rt_bvh.h FlatNode
     const uint32_t* leaf_of;     // [n_sph+n_tri] primitive -> leaf node index (= DFS rank)
     unsigned long long* counters;// [0] segments [1] candidates [2] fallbacks
@@ -627,6 +628,12 @@ __global__ __launch_bounds__(BLOCK, RT_MINWAVES) void rt_tile_kernel(const KPara
             if (seg_active) {
                 // triangles: exact test against every triangle (after the spheres in index order)
                 for (uint32_t j = 0; j < p.n_tri; j++) {
+                    // BVH semantics: a triangle the ray's own-leaf AABB test rejects was never returned by
+                    // BVH::traverse, so the reference's exact slab test doubles as the broad phase (no margin
+                    // needed: it IS the reference's candidate rule).  Linear semantics: exact test on all.
+                    if (use_bvh && p.n_sph + p.n_tri > 1 &&
+                        !intersects_aabb(o, aux, p.tri_box[2 * (size_t)j], p.tri_box[2 * (size_t)j + 1]))
+                        continue;
                     float t;
                     if (exact_triangle(o, d, p.tri + 9 * (size_t)j, p.t_min, p.t_max, t)) {
                         if (!use_bvh)

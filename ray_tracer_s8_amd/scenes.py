@@ -124,6 +124,27 @@ def quad_room(seed: int = 0x7121A9) -> tuple[np.ndarray, np.ndarray]:
     return np.array(sph, dtype=SPHERE_DTYPE), np.array(tris, dtype=TRIANGLE_DTYPE)
 
 
+def tri_terrain(nx: int = 16, nz: int = 12, seed: int = 0x7E44A1) -> tuple[np.ndarray, np.ndarray]:
+    """A height-field mesh of 2*nx*nz triangles (what an OBJ upload looks like to the slave) + 3 spheres."""
+    g = SplitMix64(seed)
+    hs = [[g.u(-1.6, -0.6) for _ in range(nx + 1)] for _ in range(nz + 1)]
+    X = lambda i: -6.0 + 12.0 * i / nx
+    Z = lambda k: -2.0 - 10.0 * k / nz
+    tris = []
+    for k in range(nz):
+        for i in range(nx):
+            p00, p10 = (X(i), hs[k][i], Z(k)), (X(i + 1), hs[k][i + 1], Z(k))
+            p01, p11 = (X(i), hs[k + 1][i], Z(k + 1)), (X(i + 1), hs[k + 1][i + 1], Z(k + 1))
+            alb = (g.u(0.3, 0.9), g.u(0.3, 0.9), g.u(0.3, 0.9))
+            rough = 0.0 if g.f() < 0.7 else g.f()
+            tris.append((p00, p10, p11, alb[0], alb[1], alb[2], rough, 0.0))
+            tris.append((p00, p11, p01, alb[0], alb[1], alb[2], rough, 0.0))
+    tris.append(((-2, 3, -5), (2, 3, -5), (0, 3.5, -8), 1.0, 1.0, 1.0, 0.0, 5.0))      # light
+    sph = [_sph((-1.5, 0.2, -4.0), 0.6, (0.9, 0.9, 0.9), 1.0), _sph((1.2, 0.0, -5.0), 0.5, (0.8, 0.3, 0.3)),
+           _sph((0.0, -0.2, -3.0), 0.3, (0.3, 0.8, 0.4), 0.4)]
+    return np.array(sph, dtype=SPHERE_DTYPE), np.array(tris, dtype=TRIANGLE_DTYPE)
+
+
 # ---- BASELINE.json configs -------------------------------------------------------------
 def config(name: str) -> tuple[np.ndarray, TileRequest]:
     """(spheres, request template) for c1..c5.  `divisions` is chosen so H % div == 0."""

@@ -164,6 +164,16 @@ def test_triangles_mixed_scene(ndev, oracle):
     _compare(oracle, rq, sph, tri)
 
 
+@pytest.mark.parametrize("flags", [0, 2])
+def test_triangle_mesh(ndev, oracle, flags):
+    # 385 triangles + 3 spheres; BVH semantics use the own-leaf AABB test as the triangle broad phase
+    sph, tri = scenes.tri_terrain()
+    rq = _abi.default_request(width=192, height=108, divisions=2, division_no=1, spp=4, max_bounces=6, seed=21)
+    _compare(oracle, rq, sph, tri, flags=flags)
+    rq.division_no = 0
+    _compare(oracle, rq, None, tri, flags=flags)            # triangles only
+
+
 def test_strips_equal_whole_frame(ndev):
     # size-independent property: per-pixel RNG streams => stitched strips == one-strip frame
     sph, rq = _small("c2", 320, 180, spp=2, div=1)
