@@ -10,6 +10,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -191,8 +192,14 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     p.bvh_nodes = sc->d_bvh;
     p.leaf_of = sc->d_leaf_of;
     p.n_strips = n;
-    p.tiles_x = (p.W + 7) / 8;
-    p.tiles_per_strip = p.tiles_x * ((p.Hs + 7) / 8);
+    // Tile shape: 64x1 keeps each tile row on whole 64-byte lines of the RGB8 strip (64 px * 3 B = 3 lines),
+    // so one CU / one XCD L2 writes every byte of a line; 8x8 tiles split lines across XCDs and doubled the
+    // HBM write traffic (profiles/).  RT_TILE_SHAPE=8x8 restores square tiles for A/B runs.
+    static const bool square = [] { const char* e = getenv("RT_TILE_SHAPE"); return e && !strcmp(e, "8x8"); }();
+    p.tile_wlog2 = (!square && p.W >= 64) ? 6u : 3u;
+    const uint32_t tw = 1u << p.tile_wlog2, th = 64u >> p.tile_wlog2;
+    p.tiles_x = (p.W + tw - 1) / tw;
+    p.tiles_per_strip = p.tiles_x * ((p.Hs + th - 1) / th);
     const uint64_t n_tiles = (uint64_t)p.tiles_per_strip * n;
     if (n_tiles > 0x7fffffffull) return fail(RT_ERR_LIMIT, "too many tiles in one launch");
     p.n_tiles = (uint32_t)n_tiles;

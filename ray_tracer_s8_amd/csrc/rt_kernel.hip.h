@@ -64,7 +64,8 @@ struct KParams {
     uint32_t lds_path_off;
     uint32_t lds_rr_off;
     uint32_t n_strips;           // strips in this launch
-    uint32_t tiles_x, tiles_per_strip, n_tiles;   // 8x8 tiles
+    uint32_t tiles_x, tiles_per_strip, n_tiles;   // tiles of 64 pixels: (1 << tile_wlog2) wide
+    uint32_t tile_wlog2;         // 3: 8x8 tiles, 6: 64x1 tiles (three whole 64-B lines of RGB8 per tile row)
     float org[3], llc[3], hor[3], ver[3];   // Camera::new (camera.rs:19-47), host-computed
     float lens_radius, focus_distance;
     float u_den, v_den;          // aspect*H_f - 1, H_f - 1 (camera.rs:115-117)
@@ -430,8 +431,8 @@ __global__ __launch_bounds__(BLOCK, RT_MINWAVES) void rt_tile_kernel(const KPara
                     const uint32_t rem = t - st * p.tiles_per_strip;
                     const uint32_t ty = rem / p.tiles_x;
                     tile_strip = st;
-                    tile_x0 = (rem - ty * p.tiles_x) * 8;
-                    tile_y0 = ty * 8;
+                    tile_x0 = (rem - ty * p.tiles_x) << p.tile_wlog2;
+                    tile_y0 = ty << (6 - p.tile_wlog2);
                     tile_yg0 = p.strips[st].y0;
                     tile_seed = p.strips[st].seed;
                     tile_pos = 0;
@@ -443,7 +444,7 @@ __global__ __launch_bounds__(BLOCK, RT_MINWAVES) void rt_tile_kernel(const KPara
                 if (need && rank < avail) {
                     WCOUNT(1);
                     const uint32_t pidx = tile_pos + rank;
-                    const uint32_t x = tile_x0 + (pidx & 7), y = tile_y0 + (pidx >> 3);
+                    const uint32_t x = tile_x0 + (pidx & ((1u << p.tile_wlog2) - 1u)), y = tile_y0 + (pidx >> p.tile_wlog2);
                     if (x < p.W && y < p.Hs) {
                         px = x;
                         pyl = y;
