@@ -53,6 +53,7 @@ std::vector<DeviceCtx*> g_ctx;
 constexpr size_t LDS_LIMIT = 160 * 1024 - 1024;   // dynamic LDS budget; 1 KiB left for the kernels' static LDS
 constexpr uint32_t RESIDENT_MAX = rtk::CHUNK;   // spheres kept wholly in LDS
 constexpr uint32_t STREAM_CHUNK = 2048;         // chunk size when streaming through LDS
+constexpr uint32_t TRAVERSE_MIN_PRIMS = 4096;   // above this many primitives the BVH-traversal engine is the default
 
 }  // namespace
 
@@ -68,6 +69,8 @@ struct rt_scene {
     float* d_tri = nullptr;
     float4* d_tri_box = nullptr;
     float4* d_bvh = nullptr;       // rtbvh::FlatNode[]
+    float4* d_trav = nullptr;      // rtbvh::TravNode[]
+    uint32_t root_ref = 0, bvh_depth = 0;
     uint32_t* d_leaf_of = nullptr;
     float bvh_build_ms = 0.f;
     unsigned long long* d_counters = nullptr;   // [0..2] stats, [4 + slot] tile queues
@@ -164,16 +167,24 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     p.n_sph_pad = sc->n_sph_pad;
     p.n_tri = sc->n_tri;
     p.flags = rq->flags;
-    const bool streamed = sc->n_sph_pad > RESIDENT_MAX;
-    p.chunk = streamed ? STREAM_CHUNK : sc->n_sph_pad;
+    // Engine choice.  BVH traversal reproduces reference semantics only, needs the tree to fit the traversal
+    // stack, and pays off once the scene is larger than a couple of LDS chunks; RT_FLAG_BVH_TRAVERSE /
+    // RT_FLAG_LINEAR_SCAN force either engine for A/B runs and tests.
+    const uint32_t n_prims = sc->n_sph + sc->n_tri;
+    const bool trav_ok = !(rq->flags & (RT_FLAG_EXACT_SCAN | RT_FLAG_NO_BVH_CULL | RT_FLAG_LINEAR_SCAN)) &&
+                         sc->bvh_depth < (uint32_t)rtk::TRAV_STACK && n_prims > 0;
+    const bool traverse = trav_ok && ((rq->flags & RT_FLAG_BVH_TRAVERSE) || n_prims > TRAVERSE_MIN_PRIMS);
+    const bool streamed = !traverse && sc->n_sph_pad > RESIDENT_MAX;
+    p.chunk = traverse ? 0 : (streamed ? STREAM_CHUNK : sc->n_sph_pad);
     p.n_chunks = p.chunk ? (sc->n_sph_pad + p.chunk - 1) / p.chunk : 0;
     p.path32 = (sc->n_sph + sc->n_tri) > 65536u ? 1u : 0u;
-    size_t geom_bytes = (size_t)(p.chunk ? p.chunk : 1) * sizeof(float4);
+    size_t geom_bytes = traverse ? 0 : (size_t)(p.chunk ? p.chunk : 1) * sizeof(float4);
     p.lds_cand_off = (uint32_t)geom_bytes;
-    size_t cand_bytes = (size_t)rtk::MAXC * rtk::BLOCK * sizeof(uint16_t);
+    size_t cand_bytes = traverse ? (size_t)rtk::MAXL * rtk::BLOCK * sizeof(uint32_t)
+                                 : (size_t)rtk::MAXC * rtk::BLOCK * sizeof(uint16_t);
     p.lds_path_off = (uint32_t)(geom_bytes + cand_bytes);
     size_t path_bytes = (size_t)p.depth * rtk::BLOCK * (p.path32 ? 4 : 2);
-    const bool expanded = sc->expanded && !(rq->flags & RT_FLAG_OC_BROAD_PHASE);
+    const bool expanded = !traverse && sc->expanded && !(rq->flags & RT_FLAG_OC_BROAD_PHASE);
     p.lds_rr_off = (uint32_t)(geom_bytes + cand_bytes + path_bytes);
     size_t rr_bytes = expanded ? (size_t)(p.chunk ? p.chunk : 1) * sizeof(float) : 0;
     size_t lds = geom_bytes + cand_bytes + path_bytes + rr_bytes;
@@ -190,6 +201,8 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     p.tri = sc->d_tri;
     p.tri_box = sc->d_tri_box;
     p.bvh_nodes = sc->d_bvh;
+    p.trav = sc->d_trav;
+    p.root_ref = sc->root_ref;
     p.leaf_of = sc->d_leaf_of;
     p.n_strips = n;
     // Tile shape: 64x1 keeps each tile row on whole 64-byte lines of the RGB8 strip (64 px * 3 B = 3 lines),
@@ -216,8 +229,10 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
 
     // persistent grid: as many workgroups as the chip holds at this LDS/VGPR budget
     int per_cu = 0;
-    void (*kern)(rtk::KParams) = streamed ? (expanded ? rtk::rt_tile_kernel<true, true> : rtk::rt_tile_kernel<true, false>)
-                                          : (expanded ? rtk::rt_tile_kernel<false, true> : rtk::rt_tile_kernel<false, false>);
+    void (*kern)(rtk::KParams) =
+        traverse ? rtk::rt_tile_kernel<2, false>
+                 : streamed ? (expanded ? rtk::rt_tile_kernel<1, true> : rtk::rt_tile_kernel<1, false>)
+                            : (expanded ? rtk::rt_tile_kernel<0, true> : rtk::rt_tile_kernel<0, false>);
     HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, rtk::BLOCK, lds));
     if (per_cu < 1) per_cu = 1;
     uint32_t blocks = (uint32_t)sc->ctx->n_cu * (uint32_t)per_cu;
@@ -341,13 +356,15 @@ RT_API int rt_init(int* n_devices) {
         c->dev = d;
         HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         HIPCHK(hipDeviceGetAttribute(&c->n_cu, hipDeviceAttributeMultiprocessorCount, d));
-        HIPCHK(hipFuncSetAttribute((const void*)rtk::rt_tile_kernel<false, false>,
+        HIPCHK(hipFuncSetAttribute((const void*)rtk::rt_tile_kernel<0, false>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
-        HIPCHK(hipFuncSetAttribute((const void*)rtk::rt_tile_kernel<false, true>,
+        HIPCHK(hipFuncSetAttribute((const void*)rtk::rt_tile_kernel<0, true>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
-        HIPCHK(hipFuncSetAttribute((const void*)rtk::rt_tile_kernel<true, false>,
+        HIPCHK(hipFuncSetAttribute((const void*)rtk::rt_tile_kernel<1, false>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
-        HIPCHK(hipFuncSetAttribute((const void*)rtk::rt_tile_kernel<true, true>,
+        HIPCHK(hipFuncSetAttribute((const void*)rtk::rt_tile_kernel<1, true>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
+        HIPCHK(hipFuncSetAttribute((const void*)rtk::rt_tile_kernel<2, false>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
         g_ctx.push_back(c);
     }
@@ -472,6 +489,9 @@ RT_API int rt_scene_create(int device, const rt_sphere* sp, uint32_t ns, const r
     sc->bvh_build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - tb0).count();
     if (bvh.nodes.empty()) bvh.nodes.push_back(rtbvh::FlatNode{{0, 0, 0}, 0xffffffffu, {0, 0, 0}, 0});
     if (bvh.leaf_of.empty()) bvh.leaf_of.push_back(0);
+    sc->root_ref = bvh.root_ref;
+    sc->bvh_depth = bvh.depth;
+    if (bvh.trav.empty()) bvh.trav.push_back(rtbvh::TravNode{});
     auto cleanup = [&](int code) {
         rt_scene_destroy(sc);
         return code;
@@ -498,6 +518,7 @@ RT_API int rt_scene_create(int device, const rt_sphere* sp, uint32_t ns, const r
     SC_CHK(hipMalloc(&sc->d_tri_box, tri_box.size() * sizeof(float4)));
     SC_CHK(hipMalloc(&sc->d_bvh, bvh.nodes.size() * sizeof(rtbvh::FlatNode)));
     SC_CHK(hipMalloc(&sc->d_leaf_of, bvh.leaf_of.size() * sizeof(uint32_t)));
+    SC_CHK(hipMalloc(&sc->d_trav, bvh.trav.size() * sizeof(rtbvh::TravNode)));
     SC_CHK(hipMalloc(&sc->d_counters, COUNTER_WORDS * sizeof(unsigned long long)));
     SC_CHK(hipEventRecord(e0, ctx->stream));
     SC_CHK(hipMemcpyAsync(sc->d_geom, geom.data(), geom.size() * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
@@ -511,6 +532,8 @@ RT_API int rt_scene_create(int device, const rt_sphere* sp, uint32_t ns, const r
     SC_CHK(hipMemcpyAsync(sc->d_tri_box, tri_box.data(), tri_box.size() * sizeof(float4), hipMemcpyHostToDevice,
                           ctx->stream));
     SC_CHK(hipMemcpyAsync(sc->d_bvh, bvh.nodes.data(), bvh.nodes.size() * sizeof(rtbvh::FlatNode), hipMemcpyHostToDevice,
+                          ctx->stream));
+    SC_CHK(hipMemcpyAsync(sc->d_trav, bvh.trav.data(), bvh.trav.size() * sizeof(rtbvh::TravNode), hipMemcpyHostToDevice,
                           ctx->stream));
     SC_CHK(hipMemcpyAsync(sc->d_leaf_of, bvh.leaf_of.data(), bvh.leaf_of.size() * sizeof(uint32_t),
                           hipMemcpyHostToDevice, ctx->stream));
@@ -545,6 +568,7 @@ RT_API void rt_scene_destroy(rt_scene* sc) {
     (void)hipFree(sc->d_tri);
     (void)hipFree(sc->d_tri_box);
     (void)hipFree(sc->d_bvh);
+    (void)hipFree(sc->d_trav);
     (void)hipFree(sc->d_leaf_of);
     (void)hipFree(sc->d_counters);
     (void)hipFree(sc->d_out);

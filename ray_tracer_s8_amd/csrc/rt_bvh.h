@@ -33,9 +33,27 @@ struct FlatNode {          // 32 bytes: two float4 on the device
     uint32_t pad;
 };
 
+// Traversal node (internal nodes only, 64 bytes = four float4 on the device): the two child AABBs the
+// crate stores in a `BVHNode::Node` plus child references.  A reference is either the index of another
+// TravNode or LEAF_BIT | primitive index.
+constexpr uint32_t LEAF_BIT = 0x80000000u;
+struct TravNode {
+    float l_lo[3];
+    uint32_t left;
+    float l_hi[3];
+    uint32_t right;
+    float r_lo[3];
+    uint32_t pad0;
+    float r_hi[3];
+    uint32_t pad1;
+};
+
 struct FlatBVH {
     std::vector<FlatNode> nodes;
     std::vector<uint32_t> leaf_of;   // primitive index -> node index (= DFS rank)
+    std::vector<TravNode> trav;      // internal nodes, root first (empty when the root is a leaf)
+    uint32_t root_ref = 0;           // reference of the root (LEAF_BIT | 0 for a single primitive)
+    uint32_t depth = 0;              // edges on the longest root-to-leaf path
 };
 
 inline Box empty_box() {
@@ -74,7 +92,10 @@ inline FlatBVH build(const std::vector<Box>& prim) {
         std::vector<uint32_t> idx;
         uint32_t parent;
         Box as_seen_by_parent;
+        bool is_right = false;
+        uint32_t depth = 0;
     };
+    std::vector<uint32_t> left_of, right_of, prim_of;   // per node (creation order)
     std::vector<Item> stack;
     {
         Item root;
@@ -98,8 +119,14 @@ inline FlatBVH build(const std::vector<Box>& prim) {
         fn.parent = it.parent;
         fn.pad = 0;
         out.nodes.push_back(fn);
+        left_of.push_back(0xffffffffu);
+        right_of.push_back(0xffffffffu);
+        prim_of.push_back(0xffffffffu);
+        if (it.parent != 0xffffffffu) (it.is_right ? right_of : left_of)[it.parent] = me;
+        if (it.depth > out.depth) out.depth = it.depth;
         if (it.idx.size() == 1) {                   // bvh_impl.rs:254-265
             out.leaf_of[it.idx[0]] = me;
+            prim_of[me] = it.idx[0];
             continue;
         }
         // convex hull of the shapes and of their centroids (:247-251)
@@ -175,9 +202,34 @@ inline FlatBVH build(const std::vector<Box>& prim) {
             if (L.idx.empty() || R.idx.empty()) halve();   // unreachable for finite centroids
         }
         // left subtree is numbered first: push right, then left
+        R.is_right = true;
+        L.depth = R.depth = it.depth + 1;
         stack.push_back(std::move(R));
         stack.push_back(std::move(L));
     }
+    // traversal form: internal nodes only, numbered in creation order
+    std::vector<uint32_t> trav_id(out.nodes.size(), 0xffffffffu);
+    uint32_t n_int = 0;
+    for (size_t n = 0; n < out.nodes.size(); n++)
+        if (prim_of[n] == 0xffffffffu) trav_id[n] = n_int++;
+    out.trav.resize(n_int);
+    auto ref_of = [&](uint32_t n) { return prim_of[n] != 0xffffffffu ? (LEAF_BIT | prim_of[n]) : trav_id[n]; };
+    for (size_t n = 0; n < out.nodes.size(); n++) {
+        if (prim_of[n] != 0xffffffffu) continue;
+        TravNode& t = out.trav[trav_id[n]];
+        const FlatNode& l = out.nodes[left_of[n]];
+        const FlatNode& r = out.nodes[right_of[n]];
+        for (int i = 0; i < 3; i++) {
+            t.l_lo[i] = l.lo[i];
+            t.l_hi[i] = l.hi[i];
+            t.r_lo[i] = r.lo[i];
+            t.r_hi[i] = r.hi[i];
+        }
+        t.left = ref_of(left_of[n]);
+        t.right = ref_of(right_of[n]);
+        t.pad0 = t.pad1 = 0;
+    }
+    out.root_ref = ref_of(0);
     return out;
 }
 

@@ -36,12 +36,15 @@ constexpr int BLOCK = 256;       // 4 waves
 #define RT_MAXC 16
 #endif
 #ifndef RT_MINWAVES
-#define RT_MINWAVES 1
+#define RT_MINWAVES 4
 #endif
 constexpr int MAXC = RT_MAXC;    // candidate list slots per lane (per chunk)
 constexpr int CHUNK = 2048;      // max spheres per LDS chunk (32 KiB): list entries carry an 8-bit group index
 constexpr int UNROLL = 8;        // broad-phase unroll; chunk sizes are padded to this
 constexpr int MAX_BATCH = 64;    // strips per launch
+constexpr int TRAV_STACK = 64;   // traversal stack entries per lane (host falls back to the linear scan beyond)
+constexpr int MAXL = 16;         // leaf-candidate slots per lane in traversal mode (flushed when full)
+constexpr uint32_t LEAF_BIT = 0x80000000u;
 
 struct StripDesc {
     uint64_t seed;
@@ -79,6 +82,9 @@ struct KParams {
     const float* emis;           // [n_sph+n_tri]
     const float* tri;            // [n_tri*9] a,b,c
     const float4* tri_box;       // [2*n_tri] Triangle::aabb (lo, hi) as the BVH sees it
+    const float4* trav;          // [4*n_internal] rtbvh::TravNode: (l_lo, left)(l_hi, right)(r_lo,-)(r_hi,-)
+    uint32_t root_ref;           // root reference (LEAF_BIT | prim when the tree is a single leaf)
+    uint32_t pad_kp;
     const float4* bvh_nodes;     // [2*n_nodes]: (lo.xyz, parent as bits) (hi.xyz, -) — rt_bvh.h FlatNode
     const uint32_t* leaf_of;     // [n_sph+n_tri] primitive -> leaf node index (= DFS rank)
     unsigned long long* counters;// [0] segments [1] candidates [2] fallbacks
@@ -364,8 +370,12 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 
 // ------------------------------------------------------------------ the kernel
-template <bool STREAMED, bool EXPANDED>
+// ISECT selects the closest-hit engine: 0 = linear scan, scene resident in LDS; 1 = linear scan, scene streamed
+// through LDS in chunks; 2 = per-lane traversal of the reference BVH (large scenes: O(log N) per ray).
+template <int ISECT, bool EXPANDED>
 __global__ __launch_bounds__(BLOCK, RT_MINWAVES) void rt_tile_kernel(const KParams p) {
+    constexpr bool STREAMED = (ISECT == 1);
+    constexpr bool TRAVERSE = (ISECT == 2);
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     float4* lgeom = reinterpret_cast<float4*>(lds_raw);          // pair layout, see KParams::geom_pk / geom_px
     const float* lgeomf = reinterpret_cast<const float*>(lds_raw);
@@ -377,7 +387,7 @@ __global__ __launch_bounds__(BLOCK, RT_MINWAVES) void rt_tile_kernel(const KPara
     const int tid = threadIdx.x;
     const int lane = tid & 63;
 
-    if (!STREAMED) {
+    if (ISECT == 0) {
         // resident scene: stage the whole primitive list into LDS once
         for (uint32_t i = tid; i < p.n_sph_pad; i += BLOCK) lgeom[i] = gsrc[i];
         if (EXPANDED)
@@ -504,161 +514,219 @@ __global__ __launch_bounds__(BLOCK, RT_MINWAVES) void rt_tile_kernel(const KPara
         const RayAux aux = ray_aux(d, (p.flags & 8u) != 0);
         const V3 td = 2.0f * d;                              // (2f32 * ray.direction), sphere.rs:44
         if (active) n_seg++;
-        bool seg_active = active;
-        bool inline_chain = false;
-        for (;;) {
-            if (seg_active) h.idx = -1;
-            for (uint32_t ch = 0; ch < p.n_chunks; ch++) {
-                const uint32_t base = ch * p.chunk;
-                const uint32_t cn = min(p.chunk, p.n_sph_pad - base);   // multiple of UNROLL
-                if (STREAMED) {
-                    __syncthreads();
-                    for (uint32_t i = tid; i < cn; i += BLOCK) lgeom[i] = gsrc[base + i];
-                    if (EXPANDED)
-                        for (uint32_t i = tid; i < cn; i += BLOCK) lrr[i] = p.geom[base + i].w;
-                    __syncthreads();
+        if constexpr (TRAVERSE) {
+            // ---- BVH::traverse (bvh_impl.rs:373-398) per lane, iteratively: depth-first, left child first, a
+            // child is entered iff the ray passes the AABB its parent stores for it.  The leaves reached ARE the
+            // reference's candidate list, in its order, so no conservative filter and no validation are needed:
+            // exact root tests on them, first minimum wins (shapes/mod.rs:158-191).
+            if (active) {
+                uint32_t* lc32 = reinterpret_cast<uint32_t*>(lds_raw + p.lds_cand_off);
+                uint32_t cnt = 0, n_leaf = 0;
+                auto flush = [&]() {
+                    for (uint32_t i = 0; i < cnt; i++) {
+                        const uint32_t prim = lc32[i * BLOCK + tid];
+                        float t;
+                        if (prim < p.n_sph) {
+                            const float4 g = p.geom[prim];
+                            if (exact_sphere(o, td, mk(g.x, g.y, g.z), g.w, p.t_min, p.t_max, t))
+                                consider<0>(h, (int)prim, o, d, t, aux, p.bvh_nodes, p.leaf_of);
+                        } else {
+                            if (exact_triangle(o, d, p.tri + 9 * (size_t)(prim - p.n_sph), p.t_min, p.t_max, t))
+                                consider<0>(h, (int)prim, o, d, t, aux, p.bvh_nodes, p.leaf_of);
+                        }
+                    }
+                    cnt = 0;
+                };
+                if (p.n_sph + p.n_tri > 0) {
+                    uint32_t stack[TRAV_STACK];
+                    int sp = 0;
+                    uint32_t ref = p.root_ref;
+                    for (;;) {
+                        if (ref & LEAF_BIT) {
+                            if (cnt == (uint32_t)MAXL) flush();
+                            lc32[cnt * BLOCK + tid] = ref & ~LEAF_BIT;
+                            cnt++;
+                            n_leaf++;
+                            if (sp == 0) break;
+                            ref = stack[--sp];
+                            continue;
+                        }
+                        const float4* __restrict__ nd = p.trav + 4 * (size_t)ref;
+                        const float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
+                        const bool hl = intersects_aabb(o, aux, n0, n1);
+                        const bool hr = intersects_aabb(o, aux, n2, n3);
+                        const uint32_t cl = __float_as_uint(n0.w), cr = __float_as_uint(n1.w);
+                        if (hl) {
+                            if (hr) stack[sp++] = cr;          // right subtree after the whole left subtree
+                            ref = cl;
+                        } else if (hr) {
+                            ref = cr;
+                        } else {
+                            if (sp == 0) break;
+                            ref = stack[--sp];
+                        }
+                    }
+                    flush();
+                }
+                n_cand += n_leaf;
+            }
+        } else {
+            bool seg_active = active;
+            bool inline_chain = false;
+            for (;;) {
+                if (seg_active) h.idx = -1;
+                for (uint32_t ch = 0; ch < p.n_chunks; ch++) {
+                    const uint32_t base = ch * p.chunk;
+                    const uint32_t cn = min(p.chunk, p.n_sph_pad - base);   // multiple of UNROLL
+                    if (STREAMED) {
+                        __syncthreads();
+                        for (uint32_t i = tid; i < cn; i += BLOCK) lgeom[i] = gsrc[base + i];
+                        if (EXPANDED)
+                            for (uint32_t i = tid; i < cn; i += BLOCK) lrr[i] = p.geom[base + i].w;
+                        __syncthreads();
+                    }
+                    if (seg_active) {
+                        uint32_t cnt = 0;
+                        if (!exact_scan) {
+                            uint32_t ncand_it = 0;
+                            // ---- broad phase: conservative "line misses sphere" rejection on sphere pairs.
+                            // The value only selects candidates (FMA allowed); the narrow phase decides.
+                            // pass = !(t < 0).  Two forms, chosen per scene by the host:
+                            //  oc form (11 packed ops / pair):  t = b'^2 + rr - L2 (1 - 2^-17),
+                            //          b' = d.(o-c), L2 = |o-c|^2
+                            //  expanded form (8 packed ops / pair):
+                            //          t = (A - d.c)^2 - (oo' + w - 2 o.c),  A = d.o, oo' = |o|^2 (1 - 2^-16),
+                            //          w = |c|^2 - rr - 2^-16 (|c|^2 + rr)  (host, rounded down)
+                            v2f k0x, k0y, k0z, k1x, k1y, k1z, kA, kB;
+                            if (EXPANDED) {
+                                const float A = __builtin_fmaf(d.z, o.z, __builtin_fmaf(d.y, o.y, d.x * o.x));
+                                const float oo =
+                                    __builtin_fmaf(o.z, o.z, __builtin_fmaf(o.y, o.y, o.x * o.x)) * (1.0f - 0x1p-16f);
+                                k0x = v2f{-d.x, -d.x}; k0y = v2f{-d.y, -d.y}; k0z = v2f{-d.z, -d.z};
+                                k1x = v2f{-2.0f * o.x, -2.0f * o.x}; k1y = v2f{-2.0f * o.y, -2.0f * o.y};
+                                k1z = v2f{-2.0f * o.z, -2.0f * o.z};
+                                kA = v2f{A, A};
+                                kB = v2f{oo, oo};
+                            } else {
+                                k0x = v2f{o.x, o.x}; k0y = v2f{o.y, o.y}; k0z = v2f{o.z, o.z};
+                                k1x = v2f{d.x, d.x}; k1y = v2f{d.y, d.y}; k1z = v2f{d.z, d.z};
+                                kA = NKM;
+                                kB = NKM;
+                            }
+                            for (uint32_t j = 0; j < cn; j += UNROLL) {
+                                float t[UNROLL];
+    #pragma unroll
+                                for (int q = 0; q < UNROLL / 2; q++) {
+                                    const float4 A4 = lgeom[j + 2 * q];
+                                    const float4 B4 = lgeom[j + 2 * q + 1];
+                                    const v2f cx = {A4.x, A4.y}, cy = {A4.z, A4.w}, cz = {B4.x, B4.y}, cw = {B4.z, B4.w};
+                                    v2f tt;
+                                    if (EXPANDED) {
+                                        const v2f bb = pk_fma(k0x, cx, pk_fma(k0y, cy, pk_fma(k0z, cz, kA)));
+                                        const v2f qq = pk_fma(k1x, cx, pk_fma(k1y, cy, pk_fma(k1z, cz, cw + kB)));
+                                        tt = pk_fma(bb, bb, -qq);
+                                    } else {
+                                        const v2f ocx = k0x - cx, ocy = k0y - cy, ocz = k0z - cz;
+                                        const v2f bb = pk_fma(k1z, ocz, pk_fma(k1y, ocy, k1x * ocx));
+                                        const v2f l2 = pk_fma(ocz, ocz, pk_fma(ocy, ocy, ocx * ocx));
+                                        tt = pk_fma(l2, kA, pk_fma(bb, bb, cw));
+                                    }
+                                    t[2 * q] = tt.x;
+                                    t[2 * q + 1] = tt.y;
+                                }
+                                // max ignores NaN; a NaN t can only come from non-finite operands, for
+                                // which the exact test reports a miss as well
+                                const float m = __builtin_fmaxf(
+                                    __builtin_fmaxf(__builtin_fmaxf(t[0], t[1]), __builtin_fmaxf(t[2], t[3])),
+                                    __builtin_fmaxf(__builtin_fmaxf(t[4], t[5]), __builtin_fmaxf(t[6], t[7])));
+                                if (!(m < 0.0f)) {
+                                    WCOUNT(4);
+                                    // one list entry per passing group of 8: (group << 8) | pass mask.  The mask
+                                    // comes from the sign bits (t >= +0 or NaN-with-clear-sign => candidate).
+                                    uint32_t neg = 0;
+    #pragma unroll
+                                    for (int q = 0; q < UNROLL; q++) neg |= (__float_as_uint(t[q]) >> 31) << q;
+                                    const uint32_t pass8 = ~neg & 0xffu;
+                                    if (cnt < (uint32_t)MAXC) lcand[cnt * BLOCK + tid] = (uint16_t)(((j >> 3) << 8) | pass8);
+                                    cnt++;
+                                    ncand_it += (uint32_t)__builtin_popcount(pass8);
+                                }
+                            }
+                            if (!inline_chain) n_cand += ncand_it;
+                        }
+                        // ---- narrow phase: the reference's exact arithmetic, ascending index order.
+                        // direct = every sphere of the chunk (exact-scan flag, or candidate list overflow)
+                        const bool direct = exact_scan || cnt > (uint32_t)MAXC;
+                        if (!exact_scan && direct && !inline_chain) n_fall++;
+                        const uint32_t n_ent = direct ? (cn >> 3) : cnt;     // groups to visit
+                        uint32_t ei = 0, grp = 0, bits = 0;
+                        for (;;) {
+                            if (bits == 0) {                                  // next list entry / next group
+                                if (ei == n_ent) break;
+                                if (direct) {
+                                    grp = ei;
+                                    bits = 0xffu;
+                                } else {
+                                    const uint32_t e = lcand[ei * BLOCK + tid];
+                                    grp = e >> 8;
+                                    bits = e & 0xffu;
+                                }
+                                ei++;
+                                if (bits == 0) continue;
+                            }
+                            WCOUNT(5);
+                            const uint32_t j = grp * 8 + (uint32_t)__builtin_ctz(bits);
+                            bits &= bits - 1;
+                            const uint32_t fo = (j >> 1) * 8 + (j & 1);                 // exact centre from the pair layout
+                            const V3 cen = mk(lgeomf[fo], lgeomf[fo + 2], lgeomf[fo + 4]);
+                            const float rr = EXPANDED ? lrr[j] : lgeomf[fo + 6];        // exact r^2
+                            float t;
+                            if (exact_sphere(o, td, cen, rr, p.t_min, p.t_max, t)) {
+                                WCOUNT(6);
+                                if (!use_bvh)
+                                    consider<0>(h, (int)(base + j), o, d, t, aux, p.bvh_nodes, p.leaf_of);
+                                else if (inline_chain)
+                                    consider<2>(h, (int)(base + j), o, d, t, aux, p.bvh_nodes, p.leaf_of);
+                                else
+                                    consider<1>(h, (int)(base + j), o, d, t, aux, p.bvh_nodes, p.leaf_of);
+                            }
+                        }
+                    }
                 }
                 if (seg_active) {
-                    uint32_t cnt = 0;
-                    if (!exact_scan) {
-                        uint32_t ncand_it = 0;
-                        // ---- broad phase: conservative "line misses sphere" rejection on sphere pairs.
-                        // The value only selects candidates (FMA allowed); the narrow phase decides.
-                        // pass = !(t < 0).  Two forms, chosen per scene by the host:
-                        //  oc form (11 packed ops / pair):  t = b'^2 + rr - L2 (1 - 2^-17),
-                        //          b' = d.(o-c), L2 = |o-c|^2
-                        //  expanded form (8 packed ops / pair):
-                        //          t = (A - d.c)^2 - (oo' + w - 2 o.c),  A = d.o, oo' = |o|^2 (1 - 2^-16),
-                        //          w = |c|^2 - rr - 2^-16 (|c|^2 + rr)  (host, rounded down)
-                        v2f k0x, k0y, k0z, k1x, k1y, k1z, kA, kB;
-                        if (EXPANDED) {
-                            const float A = __builtin_fmaf(d.z, o.z, __builtin_fmaf(d.y, o.y, d.x * o.x));
-                            const float oo =
-                                __builtin_fmaf(o.z, o.z, __builtin_fmaf(o.y, o.y, o.x * o.x)) * (1.0f - 0x1p-16f);
-                            k0x = v2f{-d.x, -d.x}; k0y = v2f{-d.y, -d.y}; k0z = v2f{-d.z, -d.z};
-                            k1x = v2f{-2.0f * o.x, -2.0f * o.x}; k1y = v2f{-2.0f * o.y, -2.0f * o.y};
-                            k1z = v2f{-2.0f * o.z, -2.0f * o.z};
-                            kA = v2f{A, A};
-                            kB = v2f{oo, oo};
-                        } else {
-                            k0x = v2f{o.x, o.x}; k0y = v2f{o.y, o.y}; k0z = v2f{o.z, o.z};
-                            k1x = v2f{d.x, d.x}; k1y = v2f{d.y, d.y}; k1z = v2f{d.z, d.z};
-                            kA = NKM;
-                            kB = NKM;
-                        }
-                        for (uint32_t j = 0; j < cn; j += UNROLL) {
-                            float t[UNROLL];
-#pragma unroll
-                            for (int q = 0; q < UNROLL / 2; q++) {
-                                const float4 A4 = lgeom[j + 2 * q];
-                                const float4 B4 = lgeom[j + 2 * q + 1];
-                                const v2f cx = {A4.x, A4.y}, cy = {A4.z, A4.w}, cz = {B4.x, B4.y}, cw = {B4.z, B4.w};
-                                v2f tt;
-                                if (EXPANDED) {
-                                    const v2f bb = pk_fma(k0x, cx, pk_fma(k0y, cy, pk_fma(k0z, cz, kA)));
-                                    const v2f qq = pk_fma(k1x, cx, pk_fma(k1y, cy, pk_fma(k1z, cz, cw + kB)));
-                                    tt = pk_fma(bb, bb, -qq);
-                                } else {
-                                    const v2f ocx = k0x - cx, ocy = k0y - cy, ocz = k0z - cz;
-                                    const v2f bb = pk_fma(k1z, ocz, pk_fma(k1y, ocy, k1x * ocx));
-                                    const v2f l2 = pk_fma(ocz, ocz, pk_fma(ocy, ocy, ocx * ocx));
-                                    tt = pk_fma(l2, kA, pk_fma(bb, bb, cw));
-                                }
-                                t[2 * q] = tt.x;
-                                t[2 * q + 1] = tt.y;
-                            }
-                            // max ignores NaN; a NaN t can only come from non-finite operands, for
-                            // which the exact test reports a miss as well
-                            const float m = __builtin_fmaxf(
-                                __builtin_fmaxf(__builtin_fmaxf(t[0], t[1]), __builtin_fmaxf(t[2], t[3])),
-                                __builtin_fmaxf(__builtin_fmaxf(t[4], t[5]), __builtin_fmaxf(t[6], t[7])));
-                            if (!(m < 0.0f)) {
-                                WCOUNT(4);
-                                // one list entry per passing group of 8: (group << 8) | pass mask.  The mask
-                                // comes from the sign bits (t >= +0 or NaN-with-clear-sign => candidate).
-                                uint32_t neg = 0;
-#pragma unroll
-                                for (int q = 0; q < UNROLL; q++) neg |= (__float_as_uint(t[q]) >> 31) << q;
-                                const uint32_t pass8 = ~neg & 0xffu;
-                                if (cnt < (uint32_t)MAXC) lcand[cnt * BLOCK + tid] = (uint16_t)(((j >> 3) << 8) | pass8);
-                                cnt++;
-                                ncand_it += (uint32_t)__builtin_popcount(pass8);
-                            }
-                        }
-                        if (!inline_chain) n_cand += ncand_it;
-                    }
-                    // ---- narrow phase: the reference's exact arithmetic, ascending index order.
-                    // direct = every sphere of the chunk (exact-scan flag, or candidate list overflow)
-                    const bool direct = exact_scan || cnt > (uint32_t)MAXC;
-                    if (!exact_scan && direct && !inline_chain) n_fall++;
-                    const uint32_t n_ent = direct ? (cn >> 3) : cnt;     // groups to visit
-                    uint32_t ei = 0, grp = 0, bits = 0;
-                    for (;;) {
-                        if (bits == 0) {                                  // next list entry / next group
-                            if (ei == n_ent) break;
-                            if (direct) {
-                                grp = ei;
-                                bits = 0xffu;
-                            } else {
-                                const uint32_t e = lcand[ei * BLOCK + tid];
-                                grp = e >> 8;
-                                bits = e & 0xffu;
-                            }
-                            ei++;
-                            if (bits == 0) continue;
-                        }
-                        WCOUNT(5);
-                        const uint32_t j = grp * 8 + (uint32_t)__builtin_ctz(bits);
-                        bits &= bits - 1;
-                        const uint32_t fo = (j >> 1) * 8 + (j & 1);                 // exact centre from the pair layout
-                        const V3 cen = mk(lgeomf[fo], lgeomf[fo + 2], lgeomf[fo + 4]);
-                        const float rr = EXPANDED ? lrr[j] : lgeomf[fo + 6];        // exact r^2
+                    // triangles: exact test against every triangle (after the spheres in index order)
+                    for (uint32_t j = 0; j < p.n_tri; j++) {
+                        // BVH semantics: a triangle the ray's own-leaf AABB test rejects was never returned by
+                        // BVH::traverse, so the reference's exact slab test doubles as the broad phase (no margin
+                        // needed: it IS the reference's candidate rule).  Linear semantics: exact test on all.
+                        if (use_bvh && p.n_sph + p.n_tri > 1 &&
+                            !intersects_aabb(o, aux, p.tri_box[2 * (size_t)j], p.tri_box[2 * (size_t)j + 1]))
+                            continue;
                         float t;
-                        if (exact_sphere(o, td, cen, rr, p.t_min, p.t_max, t)) {
-                            WCOUNT(6);
+                        if (exact_triangle(o, d, p.tri + 9 * (size_t)j, p.t_min, p.t_max, t)) {
                             if (!use_bvh)
-                                consider<0>(h, (int)(base + j), o, d, t, aux, p.bvh_nodes, p.leaf_of);
+                                consider<0>(h, (int)(p.n_sph + j), o, d, t, aux, p.bvh_nodes, p.leaf_of);
                             else if (inline_chain)
-                                consider<2>(h, (int)(base + j), o, d, t, aux, p.bvh_nodes, p.leaf_of);
+                                consider<2>(h, (int)(p.n_sph + j), o, d, t, aux, p.bvh_nodes, p.leaf_of);
                             else
-                                consider<1>(h, (int)(base + j), o, d, t, aux, p.bvh_nodes, p.leaf_of);
+                                consider<1>(h, (int)(p.n_sph + j), o, d, t, aux, p.bvh_nodes, p.leaf_of);
                         }
                     }
                 }
-            }
-            if (seg_active) {
-                // triangles: exact test against every triangle (after the spheres in index order)
-                for (uint32_t j = 0; j < p.n_tri; j++) {
-                    // BVH semantics: a triangle the ray's own-leaf AABB test rejects was never returned by
-                    // BVH::traverse, so the reference's exact slab test doubles as the broad phase (no margin
-                    // needed: it IS the reference's candidate rule).  Linear semantics: exact test on all.
-                    if (use_bvh && p.n_sph + p.n_tri > 1 &&
-                        !intersects_aabb(o, aux, p.tri_box[2 * (size_t)j], p.tri_box[2 * (size_t)j + 1]))
-                        continue;
-                    float t;
-                    if (exact_triangle(o, d, p.tri + 9 * (size_t)j, p.t_min, p.t_max, t)) {
-                        if (!use_bvh)
-                            consider<0>(h, (int)(p.n_sph + j), o, d, t, aux, p.bvh_nodes, p.leaf_of);
-                        else if (inline_chain)
-                            consider<2>(h, (int)(p.n_sph + j), o, d, t, aux, p.bvh_nodes, p.leaf_of);
-                        else
-                            consider<1>(h, (int)(p.n_sph + j), o, d, t, aux, p.bvh_nodes, p.leaf_of);
-                    }
+                // would BVH::traverse have returned the winner?  (root-to-leaf AABB chain)
+                bool redo = false;
+                if (seg_active && use_bvh && !inline_chain && h.idx >= 0) {
+                    WCOUNT(7);
+                    redo = !bvh_reaches(p.bvh_nodes, p.leaf_of[h.idx], o, aux);
                 }
+                if (STREAMED) {
+                    if (!__syncthreads_or(redo ? 1 : 0)) break;
+                } else {
+                    if (!redo) break;
+                }
+                seg_active = redo;
+                inline_chain = true;
             }
-            // would BVH::traverse have returned the winner?  (root-to-leaf AABB chain)
-            bool redo = false;
-            if (seg_active && use_bvh && !inline_chain && h.idx >= 0) {
-                WCOUNT(7);
-                redo = !bvh_reaches(p.bvh_nodes, p.leaf_of[h.idx], o, aux);
-            }
-            if (STREAMED) {
-                if (!__syncthreads_or(redo ? 1 : 0)) break;
-            } else {
-                if (!redo) break;
-            }
-            seg_active = redo;
-            inline_chain = true;
         }
         if (active) {
             // ================= shade (main.rs:114-145) =================

@@ -102,9 +102,16 @@ def test_c5_65536_spheres_streamed_full_frame(ndev, oracle):
     assert np.array_equal(rgb, ref)
     assert st.ray_segments == info["ray_segments"]
     assert st.exact_fallbacks <= st.ray_segments // 1000
-    # leaf-box shortcut of the BVH validation == walking the whole chain (RT_FLAG_FULL_CHAIN)
+    # default engine for 65 536 spheres is the BVH traversal; the LDS-streamed linear scan agrees on a strip,
+    # with the leaf-box shortcut of its BVH validation and with the whole chain walked (RT_FLAG_FULL_CHAIN)
+    r0 = rq.copy()
+    r0.division_no, r0.flags = 11, 32
+    with rt.Scene(0, rt.World(sph)) as sc:
+        lin_strip, _, st_lin = sc.render_tile(r0)
+    strip0 = rgb.size // rq.divisions
+    assert np.array_equal(lin_strip, rgb[11 * strip0:12 * strip0])
     r1 = rq.copy()
-    r1.division_no, r1.flags = 11, 8
+    r1.division_no, r1.flags = 11, 8 | 32
     with rt.Scene(0, rt.World(sph)) as sc:
         full, _, st_f = sc.render_tile(r1)
     strip = rgb.size // rq.divisions

@@ -174,6 +174,28 @@ def test_triangle_mesh(ndev, oracle, flags):
     _compare(oracle, rq, None, tri, flags=flags)            # triangles only
 
 
+@pytest.mark.parametrize("scene", ["c2", "c3", "mesh", "single", "streamed"])
+def test_bvh_traversal_engine(ndev, oracle, scene):
+    """RT_FLAG_BVH_TRAVERSE: per-lane traversal of the reference BVH == the oracle's BVH back-end, and
+    == the linear-scan engine (RT_FLAG_LINEAR_SCAN), bit for bit."""
+    tri = None
+    if scene == "c2":
+        sph, rq = _small("c2", 240, 136)
+    elif scene == "c3":
+        sph, rq = _small("c3", 240, 136, spp=4)
+    elif scene == "mesh":
+        sph, tri = scenes.tri_terrain()
+        rq = _abi.default_request(width=160, height=90, divisions=1, spp=4, max_bounces=6, seed=21)
+    elif scene == "single":
+        sph, rq = _small("c1", 64, 64)
+    else:
+        sph = scenes.rand65536(n=9000)
+        rq = _abi.default_request(width=128, height=80, divisions=1, spp=2, max_bounces=5, seed=99)
+    a = _compare(oracle, rq, sph, tri, flags=_abi.RT_FLAG_BVH_TRAVERSE)
+    b = _compare(oracle, rq, sph, tri, flags=_abi.RT_FLAG_LINEAR_SCAN)
+    assert a.ray_segments == b.ray_segments
+
+
 def test_strips_equal_whole_frame(ndev):
     # size-independent property: per-pixel RNG streams => stitched strips == one-strip frame
     sph, rq = _small("c2", 320, 180, spp=2, div=1)
