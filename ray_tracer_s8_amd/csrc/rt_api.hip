@@ -172,7 +172,7 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     // RT_FLAG_LINEAR_SCAN force either engine for A/B runs and tests.
     const uint32_t n_prims = sc->n_sph + sc->n_tri;
     const bool trav_ok = !(rq->flags & (RT_FLAG_EXACT_SCAN | RT_FLAG_NO_BVH_CULL | RT_FLAG_LINEAR_SCAN)) &&
-                         sc->bvh_depth < (uint32_t)rtk::TRAV_STACK && n_prims > 0;
+                         sc->bvh_depth < (uint32_t)rtk::TRAV_STACK && n_prims > 0;   // LDS stack: (depth + 1) KiB per workgroup
     const bool traverse = trav_ok && ((rq->flags & RT_FLAG_BVH_TRAVERSE) || n_prims > TRAVERSE_MIN_PRIMS);
     const bool streamed = !traverse && sc->n_sph_pad > RESIDENT_MAX;
     p.chunk = traverse ? 0 : (streamed ? STREAM_CHUNK : sc->n_sph_pad);
@@ -187,7 +187,9 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     const bool expanded = !traverse && sc->expanded && !(rq->flags & RT_FLAG_OC_BROAD_PHASE);
     p.lds_rr_off = (uint32_t)(geom_bytes + cand_bytes + path_bytes);
     size_t rr_bytes = expanded ? (size_t)(p.chunk ? p.chunk : 1) * sizeof(float) : 0;
-    size_t lds = geom_bytes + cand_bytes + path_bytes + rr_bytes;
+    p.lds_stack_off = (uint32_t)(geom_bytes + cand_bytes + path_bytes + rr_bytes);
+    size_t stack_bytes = traverse ? (size_t)(sc->bvh_depth + 1) * rtk::BLOCK * sizeof(uint32_t) : 0;
+    size_t lds = geom_bytes + cand_bytes + path_bytes + rr_bytes + stack_bytes;
     if (lds > LDS_LIMIT) return fail(RT_ERR_LIMIT, "LDS budget exceeded (scene chunk + path stack)");
     fill_camera(rq, p);
     p.t_min = rq->t_min;

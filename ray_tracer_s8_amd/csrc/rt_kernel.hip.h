@@ -66,6 +66,7 @@ struct KParams {
     uint32_t lds_cand_off;       // byte offsets into dynamic LDS
     uint32_t lds_path_off;
     uint32_t lds_rr_off;
+    uint32_t lds_stack_off;      // traversal engine: per-lane stack, (bvh depth + 1) x 256 x u32
     uint32_t n_strips;           // strips in this launch
     uint32_t tiles_x, tiles_per_strip, n_tiles;   // tiles of 64 pixels: (1 << tile_wlog2) wide
     uint32_t tile_wlog2;         // 3: 8x8 tiles, 6: 64x1 tiles (three whole 64-B lines of RGB8 per tile row)
@@ -418,6 +419,19 @@ __global__ __launch_bounds__(BLOCK, RT_MINWAVES) void rt_tile_kernel(const KPara
     uint32_t depth_left = 0, k = 0;
     V3 o = mk(0, 0, 0), d = mk(0, 0, 0);
     unsigned long long n_seg = 0, n_cand = 0, n_fall = 0;
+    // ---- closest-hit query state.  The linear engines finish a query inside one loop iteration; the traversal
+    // engine keeps it across iterations (in_trav) so that lanes whose traversal ended can be refilled while
+    // stragglers keep walking.
+    Hit h;
+    h.idx = -1;
+    h.dist = 0.f;
+    h.p = mk(0, 0, 0);
+    RayAux aux = ray_aux(mk(1.f, 1.f, 1.f), false);
+    V3 td = mk(0, 0, 0);
+    bool in_trav = false;
+    uint32_t t_ref = 0, t_sp = 0, t_cnt = 0;
+    uint32_t* lc32 = reinterpret_cast<uint32_t*>(lds_raw + p.lds_cand_off);     // TRAVERSE: leaf candidates (u32)
+    uint32_t* lstack = reinterpret_cast<uint32_t*>(lds_raw + p.lds_stack_off);   // TRAVERSE: per-lane stack
 
     for (;;) {
         WCOUNT(0);
@@ -507,68 +521,76 @@ __global__ __launch_bounds__(BLOCK, RT_MINWAVES) void rt_tile_kernel(const KPara
         // root-test-pass set that is itself a BVH candidate is the argmin of the BVH candidates).
         // If the winner is not a BVH candidate (the reference's false far hits, ~1e-5 of segments),
         // round 2 rescans for that lane validating every improving hit.
-        Hit h;
-        h.idx = -1;
-        h.dist = 0.f;
-        h.p = mk(0, 0, 0);
-        const RayAux aux = ray_aux(d, (p.flags & 8u) != 0);
-        const V3 td = 2.0f * d;                              // (2f32 * ray.direction), sphere.rs:44
-        if (active) n_seg++;
+        if (active && !in_trav) {                            // a new closest-hit query starts
+            h.idx = -1;
+            aux = ray_aux(d, (p.flags & 8u) != 0);
+            td = 2.0f * d;                                   // (2f32 * ray.direction), sphere.rs:44
+            n_seg++;
+            if (TRAVERSE) {
+                t_ref = p.root_ref;
+                t_sp = 0;
+                t_cnt = 0;
+                in_trav = (p.n_sph + p.n_tri) > 0;
+            }
+        }
         if constexpr (TRAVERSE) {
             // ---- BVH::traverse (bvh_impl.rs:373-398) per lane, iteratively: depth-first, left child first, a
             // child is entered iff the ray passes the AABB its parent stores for it.  The leaves reached ARE the
             // reference's candidate list, in its order, so no conservative filter and no validation are needed:
             // exact root tests on them, first minimum wins (shapes/mod.rs:158-191).
-            if (active) {
-                uint32_t* lc32 = reinterpret_cast<uint32_t*>(lds_raw + p.lds_cand_off);
-                uint32_t cnt = 0, n_leaf = 0;
-                auto flush = [&]() {
-                    for (uint32_t i = 0; i < cnt; i++) {
-                        const uint32_t prim = lc32[i * BLOCK + tid];
-                        float t;
-                        if (prim < p.n_sph) {
-                            const float4 g = p.geom[prim];
-                            if (exact_sphere(o, td, mk(g.x, g.y, g.z), g.w, p.t_min, p.t_max, t))
-                                consider<0>(h, (int)prim, o, d, t, aux, p.bvh_nodes, p.leaf_of);
-                        } else {
-                            if (exact_triangle(o, d, p.tri + 9 * (size_t)(prim - p.n_sph), p.t_min, p.t_max, t))
-                                consider<0>(h, (int)prim, o, d, t, aux, p.bvh_nodes, p.leaf_of);
-                        }
+            // Steps run until at most half of the wave's live lanes are still walking; the finished lanes are then
+            // shaded / refilled while the stragglers keep their stack (LDS) and resume in the next round.
+            auto flush = [&]() {
+                for (uint32_t i = 0; i < t_cnt; i++) {
+                    const uint32_t prim = lc32[i * BLOCK + tid];
+                    float t;
+                    if (prim < p.n_sph) {
+                        const float4 g = p.geom[prim];
+                        if (exact_sphere(o, td, mk(g.x, g.y, g.z), g.w, p.t_min, p.t_max, t))
+                            consider<0>(h, (int)prim, o, d, t, aux, p.bvh_nodes, p.leaf_of);
+                    } else {
+                        if (exact_triangle(o, d, p.tri + 9 * (size_t)(prim - p.n_sph), p.t_min, p.t_max, t))
+                            consider<0>(h, (int)prim, o, d, t, aux, p.bvh_nodes, p.leaf_of);
                     }
-                    cnt = 0;
-                };
-                if (p.n_sph + p.n_tri > 0) {
-                    uint32_t stack[TRAV_STACK];
-                    int sp = 0;
-                    uint32_t ref = p.root_ref;
-                    for (;;) {
-                        if (ref & LEAF_BIT) {
-                            if (cnt == (uint32_t)MAXL) flush();
-                            lc32[cnt * BLOCK + tid] = ref & ~LEAF_BIT;
-                            cnt++;
-                            n_leaf++;
-                            if (sp == 0) break;
-                            ref = stack[--sp];
-                            continue;
+                }
+                t_cnt = 0;
+            };
+            for (;;) {
+                const uint32_t walking = (uint32_t)__builtin_popcountll(__ballot(in_trav));
+                const uint32_t live = (uint32_t)__builtin_popcountll(__ballot(true));
+                if (walking == 0 || (walking * 2 <= live && walking < live)) break;
+                if (in_trav) {
+                    WCOUNT(5);
+                    if (t_ref & LEAF_BIT) {
+                        if (t_cnt == (uint32_t)MAXL) flush();
+                        lc32[t_cnt * BLOCK + tid] = t_ref & ~LEAF_BIT;
+                        t_cnt++;
+                        n_cand++;
+                        if (t_sp == 0) {
+                            flush();
+                            in_trav = false;
+                        } else {
+                            t_ref = lstack[--t_sp * BLOCK + tid];
                         }
-                        const float4* __restrict__ nd = p.trav + 4 * (size_t)ref;
+                    } else {
+                        const float4* __restrict__ nd = p.trav + 4 * (size_t)t_ref;
                         const float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
                         const bool hl = intersects_aabb(o, aux, n0, n1);
                         const bool hr = intersects_aabb(o, aux, n2, n3);
                         const uint32_t cl = __float_as_uint(n0.w), cr = __float_as_uint(n1.w);
                         if (hl) {
-                            if (hr) stack[sp++] = cr;          // right subtree after the whole left subtree
-                            ref = cl;
+                            if (hr) lstack[t_sp++ * BLOCK + tid] = cr;   // right subtree after the whole left subtree
+                            t_ref = cl;
                         } else if (hr) {
-                            ref = cr;
+                            t_ref = cr;
+                        } else if (t_sp == 0) {
+                            flush();
+                            in_trav = false;
                         } else {
-                            if (sp == 0) break;
-                            ref = stack[--sp];
+                            t_ref = lstack[--t_sp * BLOCK + tid];
                         }
                     }
-                    flush();
                 }
-                n_cand += n_leaf;
             }
         } else {
             bool seg_active = active;
@@ -728,7 +750,7 @@ __global__ __launch_bounds__(BLOCK, RT_MINWAVES) void rt_tile_kernel(const KPara
                 inline_chain = true;
             }
         }
-        if (active) {
+        if (active && !in_trav) {
             // ================= shade (main.rs:114-145) =================
             float term_r, term_g, term_b;
             bool finished;
