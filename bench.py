@@ -42,7 +42,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "c5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-scale", type=int, default=2, help="CPU baseline renders the frame at 1/scale resolution")
+    ap.add_argument("--cpu-scale", type=int, default=4, help="CPU baseline renders the frame at 1/scale resolution")
     ap.add_argument("--flags", type=int, default=0, help="rt_tile_request.flags (1 = exact scan)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for the barrier / timing reduce (gloo: rehearsal on one GPU)")
@@ -202,7 +202,9 @@ def main():
                 "rays": "ray segments (primary + secondary closest-hit queries)",
                 "mprimary_per_s": prim / elapsed / 1e6,
                 "segments_per_primary": segs / prim,
-                "exact_scan": bool(args.flags & 1),
+                "engine": ["linear scan, scene resident in LDS", "linear scan, scene streamed through LDS",
+                           "per-lane traversal of the reference BVH"][st.engine],
+                "flags": args.flags,
                 "broad_candidates_per_segment": float(st.broad_candidates) / max(float(st.ray_segments), 1.0),
                 "exact_fallbacks": int(st.exact_fallbacks),
             },
@@ -218,7 +220,10 @@ def main():
                 "launches": launches,
                 "algorithmic_flops_per_launch": segs_per_launch * FLOPS_PER_TEST * n_sph,
                 "note": "SURVEY 8(d): neither HBM nor MFMA binds this path; FP32 VALU does. "
-                        "achieved = ray segments/launch x 20 flop x N spheres / HIP-event launch time",
+                        "achieved = ray segments/launch x 20 flop x N spheres / HIP-event launch time, i.e. the "
+                        "ALGORITHMIC flops of the reference's linear closest-hit; the BVH-traversal engine reaches the "
+                        "same bit-exact result with O(log N) tests per segment, so its frac is an algorithmic rate, "
+                        "not an FMA issue rate (--flags 32 benches the linear engine: frac = issue-rate bound)",
                 "hbm": {
                     "algorithmic_bytes_per_launch": hbm_bytes_per_launch,
                     "achieved_GBs": hbm_bytes_per_launch / avg_launch_s / 1e9,

@@ -95,7 +95,7 @@ enum {
      * leaf-box monotonicity shortcut (A/B testing; identical images). */
     RT_FLAG_FULL_CHAIN = 1u << 3,
     /* Closest-hit engine.  Default: linear scan over the LDS-resident / LDS-streamed primitive list for
-     * scenes up to 4096 primitives, per-lane traversal of the reference BVH above that.  Both give the
+     * scenes up to 512 primitives, per-lane traversal of the reference BVH above that.  Both give the
      * reference's result bit for bit; these force one or the other (A/B runs, tests). */
     RT_FLAG_BVH_TRAVERSE = 1u << 4,
     RT_FLAG_LINEAR_SCAN = 1u << 5
@@ -133,6 +133,9 @@ typedef struct rt_tile_stats {
     float h2d_ms;               /* scene upload (0 when a resident rt_scene is used)          */
     float d2h_ms;               /* RGB8 strip download (0 for device output)                  */
     uint32_t n_launches;        /* kernel launches issued by this call                        */
+    uint32_t engine;            /* closest-hit engine of the last launch: 0 linear scan (scene resident
+                                   in LDS), 1 linear scan (scene streamed through LDS), 2 BVH traversal */
+    uint32_t broad_form;        /* linear engines: 0 = oc form, 1 = expanded form   */
 } rt_tile_stats;
 
 /* ---- lifecycle ------------------------------------------------------------------ */

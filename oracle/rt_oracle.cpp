@@ -633,7 +633,12 @@ Color ray_color(Ctx& cx, const Ray& ray, uint32_t depth, Rng& rng) {
     IntersectionTable tb;
     bool hit;
     if (sc.use_bvh) {
-        std::vector<uint32_t> cands;  // per-call, like the reference's Vec (recursion needs its own)
+        // the reference allocates a fresh Vec per call (bvh_impl.rs:436); a per-thread pool indexed by the
+        // recursion depth gives the same candidate list without the allocator traffic
+        static thread_local std::vector<std::vector<uint32_t>> pool;
+        if (pool.size() <= depth) pool.resize(depth + 1);
+        std::vector<uint32_t>& cands = pool[depth];
+        cands.clear();
         if (!sc.bvh.nodes.empty()) bvh_traverse_recursive(sc.bvh.nodes, 0, ray, cands);
         hit = intersect(sc, ray, &cands, &tb);
     } else {

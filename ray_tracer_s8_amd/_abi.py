@@ -66,7 +66,7 @@ class TileStats(C.Structure):
         ("ray_segments", C.c_uint64), ("primary_rays", C.c_uint64),
         ("broad_candidates", C.c_uint64), ("exact_fallbacks", C.c_uint64),
         ("kernel_ms", C.c_float), ("h2d_ms", C.c_float), ("d2h_ms", C.c_float),
-        ("n_launches", C.c_uint32),
+        ("n_launches", C.c_uint32), ("engine", C.c_uint32), ("broad_form", C.c_uint32),
     ]
 
 

@@ -53,7 +53,7 @@ std::vector<DeviceCtx*> g_ctx;
 constexpr size_t LDS_LIMIT = 160 * 1024 - 1024;   // dynamic LDS budget; 1 KiB left for the kernels' static LDS
 constexpr uint32_t RESIDENT_MAX = rtk::CHUNK;   // spheres kept wholly in LDS
 constexpr uint32_t STREAM_CHUNK = 2048;         // chunk size when streaming through LDS
-constexpr uint32_t TRAVERSE_MIN_PRIMS = 4096;   // above this many primitives the BVH-traversal engine is the default
+constexpr uint32_t TRAVERSE_MIN_PRIMS = 512;    // above this many primitives the BVH-traversal engine is the default (measured crossover, tools/crossover.py)
 
 }  // namespace
 
@@ -83,6 +83,7 @@ struct rt_scene {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending, free_ev;
     uint64_t primary_rays = 0;
     float h2d_ms = 0.f;
+    uint32_t last_engine = 0, last_form = 0;
     std::mutex mu;
 };
 
@@ -246,6 +247,8 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     if (rc) return rc;
     HIPCHK(hipMemsetAsync(p.queue, 0, sizeof(unsigned long long), stream));
     HIPCHK(hipEventRecord(ev.a, stream));
+    sc->last_engine = traverse ? 2u : (streamed ? 1u : 0u);
+    sc->last_form = expanded ? 1u : 0u;
     hipLaunchKernelGGL(kern, grid, block, lds, stream, p);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ev.b, stream));
@@ -284,6 +287,8 @@ int collect_locked(rt_scene* sc, rt_tile_stats* st) {
         st->n_launches = n;
         st->h2d_ms = sc->h2d_ms;
         st->d2h_ms = 0.f;
+        st->engine = sc->last_engine;
+        st->broad_form = sc->last_form;
     }
     sc->primary_rays = 0;
     sc->h2d_ms = 0.f;
@@ -798,6 +803,8 @@ RT_API int rt_render_frame(const int* devices, int n_devices, const rt_tile_requ
         tot.h2d_ms = std::max(tot.h2d_ms, sts[w].h2d_ms);
         tot.d2h_ms = std::max(tot.d2h_ms, sts[w].d2h_ms);
         tot.n_launches += sts[w].n_launches;
+        tot.engine = sts[w].engine;
+        tot.broad_form = sts[w].broad_form;
     }
     if (stats) *stats = tot;
     return RT_OK;

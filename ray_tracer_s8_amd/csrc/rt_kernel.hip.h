@@ -43,7 +43,13 @@ constexpr int CHUNK = 2048;      // max spheres per LDS chunk (32 KiB): list ent
 constexpr int UNROLL = 8;        // broad-phase unroll; chunk sizes are padded to this
 constexpr int MAX_BATCH = 64;    // strips per launch
 constexpr int TRAV_STACK = 64;   // traversal stack entries per lane (host falls back to the linear scan beyond)
-constexpr int MAXL = 16;         // leaf-candidate slots per lane in traversal mode (flushed when full)
+#ifndef RT_MAXL
+#define RT_MAXL 8
+#endif
+#ifndef RT_REFILL_EIGHTHS
+#define RT_REFILL_EIGHTHS 3
+#endif
+constexpr int MAXL = RT_MAXL;    // leaf-candidate slots per lane in traversal mode (flushed when full)
 constexpr uint32_t LEAF_BIT = 0x80000000u;
 
 struct StripDesc {
@@ -558,7 +564,7 @@ __global__ __launch_bounds__(BLOCK, RT_MINWAVES) void rt_tile_kernel(const KPara
             for (;;) {
                 const uint32_t walking = (uint32_t)__builtin_popcountll(__ballot(in_trav));
                 const uint32_t live = (uint32_t)__builtin_popcountll(__ballot(true));
-                if (walking == 0 || (walking * 2 <= live && walking < live)) break;
+                if (walking == 0 || (walking * 8 <= live * RT_REFILL_EIGHTHS && walking < live)) break;
                 if (in_trav) {
                     WCOUNT(5);
                     if (t_ref & LEAF_BIT) {
@@ -567,8 +573,7 @@ __global__ __launch_bounds__(BLOCK, RT_MINWAVES) void rt_tile_kernel(const KPara
                         t_cnt++;
                         n_cand++;
                         if (t_sp == 0) {
-                            flush();
-                            in_trav = false;
+                            in_trav = false;                 // candidates are tested together after the walk
                         } else {
                             t_ref = lstack[--t_sp * BLOCK + tid];
                         }
@@ -584,7 +589,6 @@ __global__ __launch_bounds__(BLOCK, RT_MINWAVES) void rt_tile_kernel(const KPara
                         } else if (hr) {
                             t_ref = cr;
                         } else if (t_sp == 0) {
-                            flush();
                             in_trav = false;
                         } else {
                             t_ref = lstack[--t_sp * BLOCK + tid];
@@ -592,6 +596,7 @@ __global__ __launch_bounds__(BLOCK, RT_MINWAVES) void rt_tile_kernel(const KPara
                     }
                 }
             }
+            if (active && !in_trav) flush();                 // exact root tests of the finished lanes, together
         } else {
             bool seg_active = active;
             bool inline_chain = false;
