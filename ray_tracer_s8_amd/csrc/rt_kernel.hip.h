@@ -38,6 +38,9 @@ constexpr int BLOCK = 256;       // 4 waves
 #ifndef RT_MINWAVES
 #define RT_MINWAVES 4
 #endif
+#ifndef RT_MINWAVES_TRAV
+#define RT_MINWAVES_TRAV 5
+#endif
 constexpr int MAXC = RT_MAXC;    // candidate list slots per lane (per chunk)
 constexpr int CHUNK = 2048;      // max spheres per LDS chunk (32 KiB): list entries carry an 8-bit group index
 constexpr int UNROLL = 8;        // broad-phase unroll; chunk sizes are padded to this
@@ -265,6 +268,7 @@ struct RayAux {
     V3 inv;          // 1 / direction
     bool sx, sy, sz; // direction < 0
     bool full_chain; // RT_FLAG_FULL_CHAIN: never use the leaf-box shortcut (A/B testing)
+    bool finite;     // all three inverse components finite (and the flag above clear)
 };
 __device__ __forceinline__ RayAux ray_aux(V3 d, bool full_chain) {
     RayAux a;
@@ -273,6 +277,9 @@ __device__ __forceinline__ RayAux ray_aux(V3 d, bool full_chain) {
     a.sx = d.x < 0.0f;
     a.sy = d.y < 0.0f;
     a.sz = d.z < 0.0f;
+    const float big = __builtin_inff();
+    a.finite = !full_chain && __builtin_fabsf(a.inv.x) < big && __builtin_fabsf(a.inv.y) < big &&
+               __builtin_fabsf(a.inv.z) < big;
     return a;
 }
 // ray.rs:81-112: min/max with `if x < y {x} else {y}` semantics (not IEEE minNum)
@@ -292,6 +299,20 @@ __device__ __forceinline__ bool intersects_aabb(V3 o, const RayAux& a, float4 lo
     ray_max = rmin(ray_max, z_max);
     return rmax(ray_min, 0.0f) <= ray_max;
 }
+// The same test for a ray whose inverse direction is finite (RayAux::finite): then inv has the sign of the
+// direction, lo <= hi gives (lo-o)*inv <= (hi-o)*inv for inv > 0 and >= for inv < 0 under monotone rounding, so
+// the sign-selected ray_min / ray_max are the min / max of the two products, no NaN can arise (no 0*inf), and
+// min/max differ from the crate's `if x < y` forms only in the sign of a zero, which no comparison sees.
+__device__ __forceinline__ bool intersects_aabb_finite(V3 o, const RayAux& a, float4 lo, float4 hi) {
+    const float x0 = (lo.x - o.x) * a.inv.x, x1 = (hi.x - o.x) * a.inv.x;
+    const float y0 = (lo.y - o.y) * a.inv.y, y1 = (hi.y - o.y) * a.inv.y;
+    const float z0 = (lo.z - o.z) * a.inv.z, z1 = (hi.z - o.z) * a.inv.z;
+    const float ray_min = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0, x1), __builtin_fminf(y0, y1)),
+                                          __builtin_fminf(z0, z1));
+    const float ray_max = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0, x1), __builtin_fmaxf(y0, y1)),
+                                          __builtin_fmaxf(z0, z1));
+    return __builtin_fmaxf(ray_min, 0.0f) <= ray_max;
+}
 // Would BVH::traverse (bvh_impl.rs:373-398) have returned this primitive?  Every node on the
 // leaf's path to the root must pass the AABB test its parent stores for it.
 //
@@ -302,9 +323,7 @@ __device__ __forceinline__ bool intersects_aabb(V3 o, const RayAux& a, float4 lo
 // occur.  Hence ray_min_a <= ray_min_leaf and ray_max_a >= ray_max_leaf: if the leaf's own box passes,
 // every ancestor passes.  Only when a direction component is +-0 (inv = +-inf) is the chain walked.
 __device__ __forceinline__ bool bvh_reaches(const float4* __restrict__ nodes, uint32_t node, V3 o, const RayAux& a) {
-    const float big = __builtin_inff();
-    const bool finite_inv = !a.full_chain && __builtin_fabsf(a.inv.x) < big && __builtin_fabsf(a.inv.y) < big &&
-                            __builtin_fabsf(a.inv.z) < big;
+    const bool finite_inv = a.finite;
     for (;;) {
         const float4 lo = nodes[2 * (size_t)node];
         const uint32_t parent = __float_as_uint(lo.w);
@@ -380,7 +399,7 @@ __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_el
 // ISECT selects the closest-hit engine: 0 = linear scan, scene resident in LDS; 1 = linear scan, scene streamed
 // through LDS in chunks; 2 = per-lane traversal of the reference BVH (large scenes: O(log N) per ray).
 template <int ISECT, bool EXPANDED>
-__global__ __launch_bounds__(BLOCK, RT_MINWAVES) void rt_tile_kernel(const KParams p) {
+__global__ __launch_bounds__(BLOCK, ISECT == 2 ? RT_MINWAVES_TRAV : RT_MINWAVES) void rt_tile_kernel(const KParams p) {
     constexpr bool STREAMED = (ISECT == 1);
     constexpr bool TRAVERSE = (ISECT == 2);
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -580,8 +599,14 @@ __global__ __launch_bounds__(BLOCK, RT_MINWAVES) void rt_tile_kernel(const KPara
                     } else {
                         const float4* __restrict__ nd = p.trav + 4 * (size_t)t_ref;
                         const float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
-                        const bool hl = intersects_aabb(o, aux, n0, n1);
-                        const bool hr = intersects_aabb(o, aux, n2, n3);
+                        bool hl, hr;
+                        if (aux.finite) {                    // (RT_FLAG_FULL_CHAIN also forces the crate's literal form)
+                            hl = intersects_aabb_finite(o, aux, n0, n1);
+                            hr = intersects_aabb_finite(o, aux, n2, n3);
+                        } else {
+                            hl = intersects_aabb(o, aux, n0, n1);
+                            hr = intersects_aabb(o, aux, n2, n3);
+                        }
                         const uint32_t cl = __float_as_uint(n0.w), cr = __float_as_uint(n1.w);
                         if (hl) {
                             if (hr) lstack[t_sp++ * BLOCK + tid] = cr;   // right subtree after the whole left subtree
