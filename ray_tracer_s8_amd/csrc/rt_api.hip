@@ -357,26 +357,37 @@ RT_API int rt_init(int* n_devices) {
         return fail(RT_ERR_NO_DEVICE, std::string("hipGetDeviceCount: ") +
                                           (e != hipSuccess ? hipGetErrorString(e) : "0 devices"));
     }
+    // contexts are created lazily, on the first scene of a device: a rank of a multi-process job touches
+    // only its own GPU
     for (int d = 0; d < n; d++) {
-        HIPCHK(hipSetDevice(d));
         DeviceCtx* c = new DeviceCtx;
         c->dev = d;
-        HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-        HIPCHK(hipDeviceGetAttribute(&c->n_cu, hipDeviceAttributeMultiprocessorCount, d));
-        HIPCHK(hipFuncSetAttribute((const void*)rtk::rt_tile_kernel<0, false>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
-        HIPCHK(hipFuncSetAttribute((const void*)rtk::rt_tile_kernel<0, true>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
-        HIPCHK(hipFuncSetAttribute((const void*)rtk::rt_tile_kernel<1, false>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
-        HIPCHK(hipFuncSetAttribute((const void*)rtk::rt_tile_kernel<1, true>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
-        HIPCHK(hipFuncSetAttribute((const void*)rtk::rt_tile_kernel<2, false>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
         g_ctx.push_back(c);
     }
     g_init = true;
     if (n_devices) *n_devices = n;
+    return RT_OK;
+}
+
+// Create the device's stream and raise the kernels' dynamic-LDS limit (once per device).
+static int ensure_ctx(DeviceCtx* c) {
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->stream) return RT_OK;
+    HIPCHK(hipSetDevice(c->dev));
+    HIPCHK(hipDeviceGetAttribute(&c->n_cu, hipDeviceAttributeMultiprocessorCount, c->dev));
+    HIPCHK(hipFuncSetAttribute((const void*)rtk::rt_tile_kernel<0, false>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
+    HIPCHK(hipFuncSetAttribute((const void*)rtk::rt_tile_kernel<0, true>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
+    HIPCHK(hipFuncSetAttribute((const void*)rtk::rt_tile_kernel<1, false>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
+    HIPCHK(hipFuncSetAttribute((const void*)rtk::rt_tile_kernel<1, true>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
+    HIPCHK(hipFuncSetAttribute((const void*)rtk::rt_tile_kernel<2, false>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
+    hipStream_t st = nullptr;
+    HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    c->stream = st;
     return RT_OK;
 }
 
@@ -400,6 +411,10 @@ RT_API int rt_scene_create(int device, const rt_sphere* sp, uint32_t ns, const r
     if (device < 0 || device >= (int)g_ctx.size()) return fail(RT_ERR_BAD_DEVICE, "bad device ordinal");
     if ((uint64_t)ns + nt > 0x7ffffff0ull) return fail(RT_ERR_LIMIT, "too many primitives");
     DeviceCtx* ctx = g_ctx[device];
+    {
+        int rc0 = ensure_ctx(ctx);
+        if (rc0) return rc0;
+    }
     HIPCHK(hipSetDevice(ctx->dev));
     rt_scene* sc = new (std::nothrow) rt_scene;
     if (!sc) return fail(RT_ERR_OOM, "host allocation failed");
