@@ -443,6 +443,9 @@ __global__ __launch_bounds__(BLOCK, ISECT == 2 ? RT_MINWAVES_TRAV : RT_MINWAVES)
     uint32_t s_idx = 0;          // samples finished
     uint32_t depth_left = 0, k = 0;
     V3 o = mk(0, 0, 0), d = mk(0, 0, 0);
+    bool bounce = false;         // need_ray kind: false = camera ray of a new sample, true = scattered ray
+    V3 bn = mk(0, 0, 0);         // bounce: surface normal at the hit
+    float brough = 0.f;          // bounce: roughness of the hit material
     unsigned long long n_seg = 0, n_cand = 0, n_fall = 0;
     // ---- closest-hit query state.  The linear engines finish a query inside one loop iteration; the traversal
     // engine keeps it across iterations (in_trav) so that lanes whose traversal ended can be refilled while
@@ -514,26 +517,44 @@ __global__ __launch_bounds__(BLOCK, ISECT == 2 ? RT_MINWAVES_TRAV : RT_MINWAVES)
         }
         const bool active = have_pixel;
         if (active && need_ray) {
-            // ---- Camera::get_ray (camera.rs:109-129); RNG draw order is normative
-            float a, bq;
+            // ---- next ray of the lane: the camera ray of a new sample (Camera::get_ray, camera.rs:109-129) or the
+            // scattered ray of a bounce (main.rs:119-127).  Both start with a rejection-sampled pair of
+            // Uniform(-1,1) draws — UnitDisc accepts x1^2+x2^2 <= 1, UnitSphere (Marsaglia) rejects >= 1 — and both
+            // end in Ray::new's normalisation, so the two kinds share one sampler loop and one normalize.
+            // RNG draw order per lane is the reference's.
+            float x1, x2, sm;
             WCOUNT(2);
-            for (;;) {                                   // UnitDisc
+            for (;;) {
                 WCOUNT(3);
-                a = uniform_m1_1(rng);
-                bq = uniform_m1_1(rng);
-                if (a * a + bq * bq <= 1.0f) break;
+                x1 = uniform_m1_1(rng);
+                x2 = uniform_m1_1(rng);
+                sm = x1 * x1 + x2 * x2;
+                if (bounce ? !(sm >= 1.0f) : (sm <= 1.0f)) break;
             }
-            V3 offset = mk(a * p.lens_radius, bq * p.lens_radius, 0.0f);
-            float u = (xf + gen_range_01(rng)) / p.u_den;
-            float v = (ycf + gen_range_01(rng)) / p.v_den;
-            V3 dir0 = normalize_or_zero(llc + u * hor + v * ver - corg);
-            V3 d1 = normalize(dir0);                     // Ray::new re-normalises (ray.rs:134)
-            V3 focal_point = corg + p.focus_distance * d1;
-            o = corg + offset;
-            d = normalize(normalize_or_zero(focal_point - o));
-            depth_left = p.depth;
-            k = 0;
+            V3 xdir;
+            if (bounce) {
+                const float factor = 2.0f * __builtin_sqrtf(1.0f - sm);                // UnitSphere, main.rs:119
+                const V3 us = mk(x1 * factor, x2 * factor, 1.0f - 2.0f * sm);
+                const V3 diffuse_dir = us + bn;
+                const V3 glossy_dir = d - (2.0f * dot(d, bn)) * bn;                    // main.rs:120-121
+                const V3 scatter = diffuse_dir + brough * (glossy_dir - diffuse_dir); // main.rs:122
+                if (!try_normalize(scatter, xdir)) xdir = bn;                          // main.rs:126
+                // o is already the hit point P (origin exactly P)
+            } else {
+                const V3 offset = mk(x1 * p.lens_radius, x2 * p.lens_radius, 0.0f);
+                const float u = (xf + gen_range_01(rng)) / p.u_den;
+                const float v = (ycf + gen_range_01(rng)) / p.v_den;
+                const V3 dir0 = normalize_or_zero(llc + u * hor + v * ver - corg);
+                const V3 d1 = normalize(dir0);                     // Ray::new re-normalises (ray.rs:134)
+                const V3 focal_point = corg + p.focus_distance * d1;
+                o = corg + offset;
+                xdir = normalize_or_zero(focal_point - o);
+                depth_left = p.depth;
+                k = 0;
+            }
+            d = normalize(xdir);                                   // Ray::new (ray.rs:134)
             need_ray = false;
+            bounce = false;
         }
         if (STREAMED) {
             if (!__syncthreads_or(active ? 1 : 0)) break;
@@ -803,33 +824,31 @@ __global__ __launch_bounds__(BLOCK, ISECT == 2 ? RT_MINWAVES_TRAV : RT_MINWAVES)
                         V3 A = mk(tv[0], tv[1], tv[2]), B = mk(tv[3], tv[4], tv[5]), C = mk(tv[6], tv[7], tv[8]);
                         n = normalize_or_zero(cross(A - B, A - C));                  // mesh.rs:163-165
                     }
-                    // UnitSphere (Marsaglia), main.rs:119
-                    V3 us;
-                    WCOUNT(9);
-                    for (;;) {
-                        WCOUNT(10);
-                        float x1 = uniform_m1_1(rng);
-                        float x2 = uniform_m1_1(rng);
-                        float sm = x1 * x1 + x2 * x2;
-                        if (sm >= 1.0f) continue;
-                        float factor = 2.0f * __builtin_sqrtf(1.0f - sm);
-                        us = mk(x1 * factor, x2 * factor, 1.0f - 2.0f * sm);
-                        break;
-                    }
-                    V3 diffuse_dir = us + n;
-                    V3 glossy_dir = d - (2.0f * dot(d, n)) * n;                       // main.rs:120-121
-                    V3 scatter = diffuse_dir + m.w * (glossy_dir - diffuse_dir);      // main.rs:122
-                    V3 nd;
-                    if (!try_normalize(scatter, nd)) nd = n;                          // main.rs:126
                     // push the hit on the path stack: albedo product is applied back-to-front
                     if (p.path32)
                         reinterpret_cast<uint32_t*>(lpath)[k * BLOCK + tid] = (uint32_t)h.idx;
                     else
                         reinterpret_cast<uint16_t*>(lpath)[k * BLOCK + tid] = (uint16_t)h.idx;
                     k++;
-                    o = h.p;                                                           // origin exactly P
-                    d = normalize(nd);                                                 // Ray::new
                     depth_left--;
+                    if (depth_left == 0) {
+                        // the reference still draws UnitSphere before ray_color(.., 0) returns black
+                        // (main.rs:119 then :109-111): advance the stream, the direction is never used
+                        WCOUNT(9);
+                        for (;;) {
+                            WCOUNT(10);
+                            const float y1 = uniform_m1_1(rng);
+                            const float y2 = uniform_m1_1(rng);
+                            if (!(y1 * y1 + y2 * y2 >= 1.0f)) break;
+                        }
+                    } else {
+                        // scattered ray: generated at the top of the next round together with the camera rays
+                        o = h.p;                                                       // origin exactly P
+                        bn = n;
+                        brough = m.w;
+                        bounce = true;
+                        need_ray = true;
+                    }
                     finished = (depth_left == 0);                                      // main.rs:109-111
                     term_r = term_g = term_b = 0.0f;
                 }
