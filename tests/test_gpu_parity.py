@@ -297,3 +297,53 @@ def test_http_slave_shim_on_gpu(ndev, oracle):
     finally:
         svc.stop()
         master.stop()
+
+
+@pytest.mark.parametrize("engine", [_abi.RT_FLAG_LINEAR_SCAN, _abi.RT_FLAG_BVH_TRAVERSE])
+def test_non_default_knobs(ndev, oracle, engine):
+    """Every knob the reference hard-codes, moved off its literal (camera, t window, spp, depth, 64-bit seed)."""
+    sph, _ = scenes.config("c3")
+    rq = _abi.default_request(width=150, height=110, divisions=5, division_no=3, spp=3, max_bounces=13,
+                              aperture=0.0, focus_distance=3.5, fov=1.1, focal_length=1.5, t_min=0.01, t_max=40.0,
+                              seed=0xFEDCBA9876543210, flags=engine)
+    _compare(oracle, rq, sph, flags=engine)
+    rq2 = rq.copy()
+    rq2.aperture, rq2.fov, rq2.t_max = 0.4, 2.4, 1e30
+    _compare(oracle, rq2, sph, flags=engine)
+
+
+def test_reference_literals_small_frame(ndev, oracle):
+    # the slave's own settings: 100 spp, 10 bounces, 20 divisions (main.rs:39,51; controller main.rs:33-39)
+    sph = scenes.cornell16()
+    rq = _abi.default_request(width=96, height=60, division_no=7, seed=3)      # 20 strips of 3 rows
+    assert (rq.spp, rq.max_bounces, rq.divisions) == (100, 10, 20)
+    _compare(oracle, rq, sph)
+
+
+def test_max_bounces_limit_and_mirror_box(ndev, oracle):
+    # mirror walls keep paths alive to the depth limit: path stack of 63 entries, right-to-left product
+    s = scenes.cornell16().copy()
+    s["roughness"][:5] = 1.0
+    s["albedo_r"][:5] = s["albedo_g"][:5] = s["albedo_b"][:5] = 0.98
+    s["emission"][5] = 0.0
+    back = s[:1].copy()                                   # sixth wall behind the camera closes the box
+    back["cx"], back["cy"], back["cz"] = 0.0, 0.0, 104.0
+    s = np.concatenate([s, back])
+    rq = _abi.default_request(width=64, height=40, divisions=1, spp=2, max_bounces=_abi.RT_MAX_BOUNCES, seed=9)
+    st = _compare(oracle, rq, s, flags=_abi.RT_FLAG_LINEAR_SCAN)
+    assert st.ray_segments > 64 * 40 * 2 * 40          # nothing escapes: paths run towards the depth limit
+    _compare(oracle, rq, s, flags=_abi.RT_FLAG_BVH_TRAVERSE)
+
+
+def test_more_strips_than_one_launch_holds(ndev, oracle):
+    sph, rq = _small("c2", 64, 130, spp=1, div=130)          # 130 one-row strips -> 3 launches of <= 64 strips
+    reqs = []
+    for k in range(130):
+        r = rq.copy(); r.division_no = k
+        reqs.append(r)
+    with rt.Scene(0, rt.World(sph)) as sc:
+        outs, _, st = sc.render_tiles(reqs)
+    assert st.n_launches == 3
+    whole = rq.copy(); whole.divisions = 1
+    ref, _, info = oracle.render(whole, sph, backend=1)
+    assert np.array_equal(np.concatenate(outs), ref) and st.ray_segments == info["ray_segments"]
