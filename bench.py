@@ -42,7 +42,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "c5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-scale", type=int, default=4, help="CPU baseline renders the frame at 1/scale resolution")
+    ap.add_argument("--cpu-scale", type=int, default=2, help="CPU baseline renders the frame at 1/scale resolution")
     ap.add_argument("--flags", type=int, default=0, help="rt_tile_request.flags (1 = exact scan)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for the barrier / timing reduce (gloo: rehearsal on one GPU)")

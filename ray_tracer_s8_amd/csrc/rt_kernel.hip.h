@@ -587,6 +587,7 @@ __global__ __launch_bounds__(BLOCK, ISECT == 2 ? RT_MINWAVES_TRAV : RT_MINWAVES)
             // Steps run until at most half of the wave's live lanes are still walking; the finished lanes are then
             // shaded / refilled while the stragglers keep their stack (LDS) and resume in the next round.
             auto flush = [&]() {
+#pragma clang loop unroll(disable)
                 for (uint32_t i = 0; i < t_cnt; i++) {
                     const uint32_t prim = lc32[i * BLOCK + tid];
                     float t;
