@@ -168,6 +168,17 @@ def main():
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         segs, prim = float(c[0].item()), float(c[1].item())
 
+    # PCIe-inclusive rate (never `value`): the same frame through the host-buffer entry point
+    # (rt_scene_render_tiles: kernel + one D2H copy per strip into pageable host memory), one pass, N = 1 only
+    pcie = None
+    if rank == 0 and world == 1:
+        th0 = time.perf_counter()
+        _, _, st_h = scene.render_tiles(reqs)
+        th1 = time.perf_counter()
+        pcie = {"ms_per_frame_host_buffers": (th1 - th0) * 1e3, "kernel_ms": st_h.kernel_ms, "d2h_ms": st_h.d2h_ms,
+                "mrays_per_s": float(st_h.ray_segments) / (th1 - th0) / 1e6,
+                "scene_h2d_bytes": int(36 * len(sph))}
+
     if rank == 0:
         n_sph = len(sph)
         launches = max(st.n_launches, 1)
@@ -205,6 +216,7 @@ def main():
                 "engine": ["linear scan, scene resident in LDS", "linear scan, scene streamed through LDS",
                            "per-lane traversal of the reference BVH"][st.engine],
                 "flags": args.flags,
+                "pcie_inclusive": pcie,
                 "broad_candidates_per_segment": float(st.broad_candidates) / max(float(st.ray_segments), 1.0),
                 "exact_fallbacks": int(st.exact_fallbacks),
             },

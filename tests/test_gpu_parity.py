@@ -347,3 +347,17 @@ def test_more_strips_than_one_launch_holds(ndev, oracle):
     whole = rq.copy(); whole.divisions = 1
     ref, _, info = oracle.render(whole, sph, backend=1)
     assert np.array_equal(np.concatenate(outs), ref) and st.ray_segments == info["ray_segments"]
+
+
+@pytest.mark.parametrize("flags", [_abi.RT_FLAG_LINEAR_SCAN, _abi.RT_FLAG_BVH_TRAVERSE, _abi.RT_FLAG_NO_BVH_CULL])
+def test_exact_distance_ties_follow_the_reference_order(ndev, oracle, flags):
+    """Coincident spheres with different albedos: every hit is an exact distance tie.  The reference keeps the
+    first minimum of the BVH traversal output (DFS leaf order; its build halves index lists when all centroids
+    coincide), the linear semantics the lowest index."""
+    base = scenes.cornell16()
+    dup = np.repeat(base[6:9], 5, axis=0).copy()            # three small spheres, five copies each
+    rng = np.random.default_rng(3)
+    dup["albedo_r"], dup["albedo_g"], dup["albedo_b"] = rng.uniform(0.1, 0.9, (3, len(dup))).astype(np.float32)
+    sph = np.concatenate([base, dup])
+    rq = _abi.default_request(width=160, height=90, divisions=1, spp=4, max_bounces=4, seed=17)
+    _compare(oracle, rq, sph, flags=flags)

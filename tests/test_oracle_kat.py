@@ -251,3 +251,12 @@ def test_linear_and_bvh_backends_agree(oracle):
         a, af, ia = oracle.render(rq, sphs, backend=0, want_f32=True)
         b, bf, ib = oracle.render(rq, sphs, backend=1, want_f32=True)
         assert np.array_equal(a, b) and np.array_equal(af, bf) and ia["ray_segments"] == ib["ray_segments"]
+
+
+def test_coincident_spheres_bvh_vs_linear_winner(oracle):
+    # all centroids equal -> the crate splits the index list in half (bvh_impl.rs:277-291); DFS order of the
+    # leaves is then the index order, so both back-ends agree on the winner of an exact tie
+    s = np.concatenate([sph((0, 0, -3), 1.0, alb=(a, 0, 0)) for a in (0.1, 0.2, 0.3, 0.4, 0.5)])
+    a = oracle.intersect(s, None, (0, 0, 0), (0, 0, -1), backend=0)
+    b = oracle.intersect(s, None, (0, 0, 0), (0, 0, -1), backend=1)
+    assert a["index"] == 0 and b["index"] == 0
