@@ -42,13 +42,26 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "c5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-scale", type=int, default=2, help="CPU baseline renders the frame at 1/scale resolution")
+    ap.add_argument("--cpu-scale", type=int, default=1, help="CPU baseline renders the frame at 1/scale resolution")
     ap.add_argument("--flags", type=int, default=0, help="rt_tile_request.flags (1 = exact scan)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for the barrier / timing reduce (gloo: rehearsal on one GPU)")
     ap.add_argument("--share-device", action="store_true",
                     help="rehearsal only: all ranks use GPU 0 (a one-GPU box cannot run RCCL with 2 ranks)")
     return ap.parse_args()
+
+
+def effective_cpus() -> int:
+    """Host cores this process may really use: affinity mask capped by the cgroup CPU quota (the GPU box
+    exposes 256 hardware threads but grants a 16-CPU share per GPU)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except Exception:
+        pass
+    return max(1, n)
 
 
 def cpu_baseline(workload: str, scale: int):
@@ -60,7 +73,7 @@ def cpu_baseline(workload: str, scale: int):
     rq.height //= scale
     rq.divisions = 1
     rq.division_no = 0
-    threads = orc.hardware_threads()
+    threads = effective_cpus()
     _, _, info = orc.render(rq, sph, backend=1, nthreads=threads)
     secs = info["render_ms"] / 1e3
     return {
@@ -70,7 +83,7 @@ def cpu_baseline(workload: str, scale: int):
         "kind": "port",
         "sample": (f"{workload} scene, same spp/depth/seed, full frame at 1/{scale} resolution "
                    f"({rq.width}x{rq.height}); C++ oracle with the reference's SAH-BVH candidate filter, "
-                   f"rows over all host threads; {info['ray_segments']} ray segments in {secs:.2f} s "
+                   f"64-pixel spans over all usable host cores; {info['ray_segments']} ray segments in {secs:.2f} s "
                    f"(+{info['bvh_build_ms']:.1f} ms BVH build); omits the Rust slave's per-ray heap "
                    "allocations, so optimistic for the reference"),
         "cpu_seconds": secs * threads,
