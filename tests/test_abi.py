@@ -120,3 +120,24 @@ def test_product_package_never_imports_the_oracle():
         assert not re.search(r"^\s*(import|from)\s+oracle\b", txt, re.M), f
         assert not re.search(r"#\s*include\s*[<\"][^>\"]*oracle", txt), f
         assert "librt_oracle" not in txt and "rt_oracle_" not in txt, f
+
+
+def test_header_is_valid_c99_and_c_client_links(tmp_path):
+    """The boundary is plain C: the header compiles as C99 and a C client links against librt_s8.so."""
+    import shutil, subprocess
+    gcc = shutil.which("gcc")
+    assert gcc
+    r = subprocess.run([gcc, "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-x", "c",
+                        str(ROOT / "include" / "rt_tile.h")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    _abi.load()
+    exe = tmp_path / "render_frame"
+    r = subprocess.run([gcc, "-std=c99", "-O2", "-Wall", f"-I{ROOT / 'include'}", str(ROOT / "examples" / "render_frame.c"),
+                        f"-L{_abi.lib_path().parent}", "-lrt_s8", f"-Wl,-rpath,{_abi.lib_path().parent}",
+                        "-Wl,-rpath-link,/opt/rocm/lib", "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    run = subprocess.run([str(exe), str(tmp_path / "f.ppm")], capture_output=True, text=True)
+    if run.returncode == 2:                       # CPU container: rt_init reports no device, loudly
+        assert "no HIP device" in run.stderr
+    else:
+        assert run.returncode == 0 and "C_CLIENT_OK" in run.stdout, run.stdout + run.stderr

@@ -361,3 +361,20 @@ def test_exact_distance_ties_follow_the_reference_order(ndev, oracle, flags):
     sph = np.concatenate([base, dup])
     rq = _abi.default_request(width=160, height=90, divisions=1, spp=4, max_bounces=4, seed=17)
     _compare(oracle, rq, sph, flags=flags)
+
+
+def test_plain_c_client(ndev, tmp_path):
+    """examples/render_frame.c through the C-ABI only (no Python binding in the loop)."""
+    import shutil, subprocess
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    exe = tmp_path / "render_frame"
+    lib = _abi.lib_path().parent
+    r = subprocess.run([shutil.which("gcc"), "-std=c99", "-O2", f"-I{root / 'include'}", str(root / "examples" / "render_frame.c"),
+                        f"-L{lib}", "-lrt_s8", f"-Wl,-rpath,{lib}", "-Wl,-rpath-link,/opt/rocm/lib", "-o", str(exe)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    run = subprocess.run([str(exe), str(tmp_path / "f.ppm")], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0 and "C_CLIENT_OK" in run.stdout, run.stdout + run.stderr
+    ppm = (tmp_path / "f.ppm").read_bytes()
+    assert ppm.startswith(b"P6\n256 160\n255\n") and len(ppm) == 15 + 256 * 160 * 3
