@@ -142,7 +142,7 @@ int get_events(rt_scene* sc, EvPair& ev) {
     return RT_OK;
 }
 
-constexpr uint32_t QUEUE_SLOTS = 1024;           // uncollected launches per scene
+constexpr uint32_t QUEUE_SLOTS = 16384;          // uncollected launches per scene (one 8-byte queue head each)
 constexpr uint32_t COUNTER_WORDS = 4 + QUEUE_SLOTS;
 
 bool same_frame(const rt_tile_request& a, const rt_tile_request& b) {

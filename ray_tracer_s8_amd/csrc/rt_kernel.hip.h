@@ -381,12 +381,12 @@ __device__ __forceinline__ uint8_t f32_as_u8(float v) {
 }
 
 // Phase census for tuning (compile with -DRT_PROFILE_PHASES; tools/phase_census.py): one count per wave
-// each time the code is reached by at least one lane.  Counters live in the spare queue slots [512..].
+// each time the code is reached by at least one lane.  Counters live in the spare queue slots [8192..].
 #ifdef RT_PROFILE_PHASES
 #define WCOUNT(slot)                                                                         \
     do {                                                                                     \
         unsigned long long _m = __ballot(1);                                                 \
-        if ((int)(threadIdx.x & 63) == (int)__builtin_ctzll(_m)) atomicAdd(&p.counters[4 + 512 + (slot)], 1ull); \
+        if ((int)(threadIdx.x & 63) == (int)__builtin_ctzll(_m)) atomicAdd(&p.counters[4 + 8192 + (slot)], 1ull); \
     } while (0)
 #else
 #define WCOUNT(slot) do { } while (0)

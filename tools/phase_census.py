@@ -24,7 +24,7 @@ with rt.Scene(0, rt.World(sph)) as sc:
     # counters pointer is not exported; re-render with stats only: use rt_debug_counters
     buf = (C.c_ulonglong * 32)()
     lib.rt_debug_read_counters.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
-    lib.rt_debug_read_counters(sc._h, 4 + 512, 32, buf)
+    lib.rt_debug_read_counters(sc._h, 4 + 8192, 32, buf)
     it = buf[0]
     print(f"segments {st.ray_segments}  wave-iterations {it}  lanes/iter {st.ray_segments / it:.1f}")
     for i, n in enumerate(names):
