@@ -378,3 +378,51 @@ def test_plain_c_client(ndev, tmp_path):
     assert run.returncode == 0 and "C_CLIENT_OK" in run.stdout, run.stdout + run.stderr
     ppm = (tmp_path / "f.ppm").read_bytes()
     assert ppm.startswith(b"P6\n256 160\n255\n") and len(ppm) == 15 + 256 * 160 * 3
+
+
+def _skewer_scene(n=240):
+    """n overlapping spheres threaded on the view axis: a central ray crosses every one of them."""
+    z = -3.0 - 0.25 * np.arange(n, dtype=np.float32)
+    s = np.zeros(n, _abi.SPHERE_DTYPE)
+    s["cz"], s["radius"] = z, 0.2
+    s["cx"] = 0.002 * np.sin(np.arange(n)).astype(np.float32)
+    s["albedo_r"], s["albedo_g"], s["albedo_b"] = 0.7, 0.6, 0.5
+    s["roughness"] = (np.arange(n) % 3 == 0).astype(np.float32)
+    return s
+
+
+def test_candidate_list_overflow_paths(ndev, oracle):
+    """More candidates than the per-lane lists hold: the linear engine must fall back to the exact scan of the
+    chunk (exact_fallbacks > 0), the traversal engine must flush its leaf list in mid-walk."""
+    sph = _skewer_scene()
+    rq = _abi.default_request(width=64, height=64, divisions=1, spp=2, max_bounces=3, aperture=0.0, fov=0.05, seed=4)
+    st = _compare(oracle, rq, sph, flags=_abi.RT_FLAG_LINEAR_SCAN)
+    assert st.exact_fallbacks > 0
+    st = _compare(oracle, rq, sph, flags=_abi.RT_FLAG_LINEAR_SCAN | _abi.RT_FLAG_OC_BROAD_PHASE)
+    assert st.exact_fallbacks > 0
+    st = _compare(oracle, rq, sph, flags=_abi.RT_FLAG_BVH_TRAVERSE)
+    assert st.broad_candidates > 20 * st.ray_segments // 4          # dozens of leaves per primary ray
+    _compare(oracle, rq, sph, flags=_abi.RT_FLAG_NO_BVH_CULL)
+
+
+def test_two_host_threads_on_one_device(ndev):
+    """rt_render_frame with devices = [0, 0]: two dispatcher threads, each with its own scene, share GPU 0."""
+    sph, rq = _small("c2", 320, 180, spp=2, div=6)
+    a, st_a = rt.render_frame_native(rt.World(sph), rq, devices=[0, 0])
+    b, st_b = rt.render_frame_native(rt.World(sph), rq, devices=[0])
+    assert np.array_equal(a, b) and st_a.ray_segments == st_b.ray_segments
+    assert st_a.n_launches == 2 and st_b.n_launches == 1
+
+
+def test_python_controller_and_slave_mirror(ndev, oracle):
+    from ray_tracer_s8_amd.interface import Controller, RenderMeta, RenderSettings, World
+    sph = scenes.cornell16()
+    ctl = Controller(devices=[0])
+    try:
+        meta = RenderMeta(height=60, width=96, divisions=4)
+        img = ctl.render_frame(World(sph), meta, RenderSettings(spp=3, max_bounces=4, seed=8))
+    finally:
+        ctl.close()
+    rq = _abi.default_request(width=96, height=60, divisions=1, spp=3, max_bounces=4, seed=8)
+    ref, _, _ = oracle.render(rq, sph, backend=1)
+    assert np.array_equal(img.reshape(-1), ref)
