@@ -426,3 +426,31 @@ def test_python_controller_and_slave_mirror(ndev, oracle):
     rq = _abi.default_request(width=96, height=60, divisions=1, spp=3, max_bounces=4, seed=8)
     ref, _, _ = oracle.render(rq, sph, backend=1)
     assert np.array_equal(img.reshape(-1), ref)
+
+
+def test_controller_shim_with_gpu_slaves(ndev, oracle):
+    """/upload -> in-process GPU slaves -> /poll -> JPEG: 'the controller dispatches tiles to GPUs'."""
+    import io, time, urllib.request, uuid
+    PIL = pytest.importorskip("PIL.Image")
+    from ray_tracer_s8_amd import obj
+    from ray_tracer_s8_amd.controller_shim import ControllerService
+    from ray_tracer_s8_amd.interface import RenderSettings
+    from test_obj import MTL, OBJ
+    ctl = ControllerService(devices=[0], host="127.0.0.1", port=0, width=96, height=64, divisions=4,
+                            settings=RenderSettings(spp=8, max_bounces=4, seed=5)).start()
+    post = lambda path, data: urllib.request.urlopen(
+        urllib.request.Request(f"http://127.0.0.1:{ctl.port}{path}", data=data, method="POST"), timeout=60).read()
+    try:
+        job = post(f"/upload/{len(OBJ)}/", OBJ + MTL).decode()
+        out = b""
+        for _ in range(400):
+            out = post("/poll", job.encode())
+            if out[:2] == b"\xff\xd8":
+                break
+            time.sleep(0.02)
+        img = np.asarray(PIL.open(io.BytesIO(out)).convert("RGB")).astype(np.float64)
+        rq = _abi.default_request(width=96, height=64, divisions=1, spp=8, max_bounces=4, seed=5)
+        ref, _, _ = oracle.render(rq, None, obj.build_world(OBJ + MTL, len(OBJ)), backend=1)
+        assert np.abs(img - ref.reshape(64, 96, 3)).mean() < 6.0
+    finally:
+        ctl.stop()
