@@ -49,6 +49,9 @@ constexpr int TRAV_STACK = 64;   // traversal stack entries per lane (host falls
 #ifndef RT_MAXL
 #define RT_MAXL 8
 #endif
+#ifndef RT_STEPS_PER_CHECK
+#define RT_STEPS_PER_CHECK 8
+#endif
 #ifndef RT_REFILL_EIGHTHS
 #define RT_REFILL_EIGHTHS 3
 #endif
@@ -606,6 +609,8 @@ __global__ __launch_bounds__(BLOCK, ISECT == 2 ? RT_MINWAVES_TRAV : RT_MINWAVES)
                 const uint32_t walking = (uint32_t)__builtin_popcountll(__ballot(in_trav));
                 const uint32_t live = (uint32_t)__builtin_popcountll(__ballot(true));
                 if (walking == 0 || (walking * 8 <= live * RT_REFILL_EIGHTHS && walking < live)) break;
+#pragma unroll
+                for (int rep = 0; rep < RT_STEPS_PER_CHECK; rep++)
                 if (in_trav) {
                     WCOUNT(5);
                     if (t_ref & LEAF_BIT) {
