@@ -257,12 +257,6 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     return RT_OK;
 }
 
-int launch_tile(rt_scene* sc, const rt_tile_request* rq, void* d_rgb, void* d_f32, hipStream_t stream) {
-    void* rgb[1] = {d_rgb};
-    void* f32[1] = {d_f32};
-    return launch_batch(sc, rq, 1, rgb, d_f32 ? f32 : nullptr, stream);
-}
-
 int collect_locked(rt_scene* sc, rt_tile_stats* st) {
     float ms = 0.f;
     uint32_t n = 0;
