@@ -391,8 +391,17 @@ __device__ __forceinline__ uint8_t f32_as_u8(float v) {
         unsigned long long _m = __ballot(1);                                                 \
         if ((int)(threadIdx.x & 63) == (int)__builtin_ctzll(_m)) atomicAdd(&p.counters[4 + 8192 + (slot)], 1ull); \
     } while (0)
+#define LCOUNT(slot)                                                                         \
+    do {                                                                                     \
+        unsigned long long _m = __ballot(1);                                                 \
+        if ((int)(threadIdx.x & 63) == (int)__builtin_ctzll(_m)) {                           \
+            atomicAdd(&p.counters[4 + 8192 + 32 + (slot)], (unsigned long long)__builtin_popcountll(_m)); \
+            atomicAdd(&p.counters[4 + 8192 + 64 + (slot)], 1ull);                            \
+        }                                                                                    \
+    } while (0)
 #else
 #define WCOUNT(slot) do { } while (0)
+#define LCOUNT(slot) do { } while (0)
 #endif
 
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -498,6 +507,7 @@ __global__ __launch_bounds__(BLOCK, ISECT == 2 ? RT_MINWAVES_TRAV : RT_MINWAVES)
                 const uint32_t want = (uint32_t)__builtin_popcountll(mask);
                 if (need && rank < avail) {
                     WCOUNT(1);
+                    LCOUNT(0);
                     const uint32_t pidx = tile_pos + rank;
                     const uint32_t x = tile_x0 + (pidx & ((1u << p.tile_wlog2) - 1u)), y = tile_y0 + (pidx >> p.tile_wlog2);
                     if (x < p.W && y < p.Hs) {
@@ -529,13 +539,16 @@ __global__ __launch_bounds__(BLOCK, ISECT == 2 ? RT_MINWAVES_TRAV : RT_MINWAVES)
             WCOUNT(2);
             for (;;) {
                 WCOUNT(3);
+                LCOUNT(1);
                 x1 = uniform_m1_1(rng);
                 x2 = uniform_m1_1(rng);
                 sm = x1 * x1 + x2 * x2;
                 if (bounce ? !(sm >= 1.0f) : (sm <= 1.0f)) break;
             }
             V3 xdir;
+            LCOUNT(2);
             if (bounce) {
+                LCOUNT(3);
                 const float factor = 2.0f * __builtin_sqrtf(1.0f - sm);                // UnitSphere, main.rs:119
                 const V3 us = mk(x1 * factor, x2 * factor, 1.0f - 2.0f * sm);
                 const V3 diffuse_dir = us + bn;
@@ -544,6 +557,7 @@ __global__ __launch_bounds__(BLOCK, ISECT == 2 ? RT_MINWAVES_TRAV : RT_MINWAVES)
                 if (!try_normalize(scatter, xdir)) xdir = bn;                          // main.rs:126
                 // o is already the hit point P (origin exactly P)
             } else {
+                LCOUNT(4);
                 const V3 offset = mk(x1 * p.lens_radius, x2 * p.lens_radius, 0.0f);
                 const float u = (xf + gen_range_01(rng)) / p.u_den;
                 const float v = (ycf + gen_range_01(rng)) / p.v_den;
@@ -592,6 +606,7 @@ __global__ __launch_bounds__(BLOCK, ISECT == 2 ? RT_MINWAVES_TRAV : RT_MINWAVES)
             auto flush = [&]() {
 #pragma clang loop unroll(disable)
                 for (uint32_t i = 0; i < t_cnt; i++) {
+                    LCOUNT(6);
                     const uint32_t prim = lc32[i * BLOCK + tid];
                     float t;
                     if (prim < p.n_sph) {
@@ -613,6 +628,7 @@ __global__ __launch_bounds__(BLOCK, ISECT == 2 ? RT_MINWAVES_TRAV : RT_MINWAVES)
                 for (int rep = 0; rep < RT_STEPS_PER_CHECK; rep++)
                 if (in_trav) {
                     WCOUNT(5);
+                    LCOUNT(5);
                     if (t_ref & LEAF_BIT) {
                         if (t_cnt == (uint32_t)MAXL) flush();
                         lc32[t_cnt * BLOCK + tid] = t_ref & ~LEAF_BIT;
@@ -811,8 +827,10 @@ __global__ __launch_bounds__(BLOCK, ISECT == 2 ? RT_MINWAVES_TRAV : RT_MINWAVES)
             // ================= shade (main.rs:114-145) =================
             float term_r, term_g, term_b;
             bool finished;
+            LCOUNT(7);
             if (h.idx >= 0) {
                 WCOUNT(8);
+                LCOUNT(8);
                 const float em = p.emis[h.idx];
                 const float4 m = p.mat[h.idx];
                 if (em > 0.0f) {                              // main.rs:116-117
@@ -860,6 +878,7 @@ __global__ __launch_bounds__(BLOCK, ISECT == 2 ? RT_MINWAVES_TRAV : RT_MINWAVES)
                 }
             } else {
                 WCOUNT(11);
+                LCOUNT(9);
                 // sky (main.rs:135-144)
                 float t = normalize_or_zero(d).y * 0.5f + 1.0f;
                 float omt = 1.0f - t;
@@ -870,9 +889,11 @@ __global__ __launch_bounds__(BLOCK, ISECT == 2 ? RT_MINWAVES_TRAV : RT_MINWAVES)
             }
             if (finished) {
                 WCOUNT(12);
+                LCOUNT(10);
                 // a1 (.) (a2 (.) ( ... (ak (.) terminal))) : right-to-left (main.rs:123)
                 for (uint32_t i = k; i-- > 0;) {
                     WCOUNT(13);
+                    LCOUNT(11);
                     uint32_t idx = p.path32 ? reinterpret_cast<uint32_t*>(lpath)[i * BLOCK + tid]
                                             : (uint32_t) reinterpret_cast<uint16_t*>(lpath)[i * BLOCK + tid];
                     float4 m = p.mat[idx];
@@ -887,6 +908,7 @@ __global__ __launch_bounds__(BLOCK, ISECT == 2 ? RT_MINWAVES_TRAV : RT_MINWAVES)
                 need_ray = true;
                 if (s_idx == p.spp) {
                     WCOUNT(14);
+                    LCOUNT(12);
                     // ---- mean, gamma, quantise, store (main.rs:78-81)
                     float r = __builtin_sqrtf(sum_r / p.spp_f);
                     float g = __builtin_sqrtf(sum_g / p.spp_f);

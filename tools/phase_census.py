@@ -29,5 +29,14 @@ with rt.Scene(0, rt.World(sph)) as sc:
     print(f"segments {st.ray_segments}  wave-iterations {it}  lanes/iter {st.ray_segments / it:.1f}")
     for i, n in enumerate(names):
         print(f"  [{i:2d}] {n:28s} {buf[i]:12d}   per iteration {buf[i] / it:7.3f}")
+    lbuf = (C.c_ulonglong * 64)()
+    lib.rt_debug_read_counters(sc._h, 4 + 8192 + 32, 64, lbuf)
+    lnames = ["pixel acquisition", "sampler loop round", "ray generation (common)", "  bounce part", "  camera part",
+              "traversal step", "root-test (flush) round", "shade classify", "  hit branch", "  sky branch", "finish path",
+              "  path product round", "pixel finalize"]
+    print("active lanes per execution (of 64):")
+    for i, n in enumerate(lnames):
+        if lbuf[32 + i]:
+            print(f"  {n:28s} executions/iter {lbuf[32 + i] / it:7.3f}   mean active lanes {lbuf[i] / lbuf[32 + i]:5.1f}")
 os.environ["RT_EXTRA_HIPCC_FLAGS"] = ""
 build.build(force=True)
