@@ -95,6 +95,17 @@ def test_c4_8k_strip_sample_and_properties(ndev, oracle):
     assert st.ray_segments == segs
 
 
+def test_c4_full_8k_frame_bit_exact(ndev, oracle):
+    """The whole 7680x4320 / 16 spp frame (1.03e9 ray segments), 32 strips in one launch, against the oracle."""
+    sph, rq = scenes.config("c4")
+    rgb, _, st = _frame_gpu(sph, rq)
+    whole = rq.copy()
+    whole.divisions, whole.division_no = 1, 0
+    ref, _, info = oracle.render(whole, sph, backend=1)
+    assert np.array_equal(rgb, ref)
+    assert st.ray_segments == info["ray_segments"] and st.primary_rays == 7680 * 4320 * 16
+
+
 def test_c5_65536_spheres_streamed_full_frame(ndev, oracle):
     sph, rq = scenes.config("c5")                      # scene > LDS: streamed through LDS chunks
     rgb, _, st = _frame_gpu(sph, rq)                    # the whole 4K frame, 16 strips, one launch
