@@ -140,13 +140,9 @@ def main():
         reqs.append(r)
 
     out_ptrs = [out.data_ptr() + i * strip_bytes for i in range(len(reqs))]
-    # all strips owned by this rank that share a frame seed go out as one batched launch
-    groups = {}
-    for r, ptr in zip(reqs, out_ptrs):
-        groups.setdefault(r.seed, ([], []))
-        groups[r.seed][0].append(r)
-        groups[r.seed][1].append(ptr)
-    batches = [(rs, ps) for rs, ps in groups.values()]
+    # all strips owned by this rank go out as ONE batched launch per step: a batch may mix division_no and
+    # seed (frames), every other field is the frame's (rt_scene_render_tiles_device)
+    batches = [(reqs, out_ptrs)]
 
     def step():
         for rs, ps in batches:
