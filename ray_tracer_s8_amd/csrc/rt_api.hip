@@ -53,6 +53,7 @@ std::vector<DeviceCtx*> g_ctx;
 constexpr size_t LDS_LIMIT = 160 * 1024 - 1024;   // dynamic LDS budget; 1 KiB left for the kernels' static LDS
 constexpr uint32_t RESIDENT_MAX = rtk::CHUNK;   // spheres kept wholly in LDS
 constexpr uint32_t STREAM_CHUNK = 2048;         // chunk size when streaming through LDS
+constexpr uint32_t TRAVERSE_MIN_TRIS = 64;      // ... or above this many triangles
 constexpr uint32_t TRAVERSE_MIN_PRIMS = 512;    // above this many primitives the BVH-traversal engine is the default (measured crossover, tools/crossover.py)
 
 }  // namespace
@@ -174,7 +175,9 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     const uint32_t n_prims = sc->n_sph + sc->n_tri;
     const bool trav_ok = !(rq->flags & (RT_FLAG_EXACT_SCAN | RT_FLAG_NO_BVH_CULL | RT_FLAG_LINEAR_SCAN)) &&
                          sc->bvh_depth < (uint32_t)rtk::TRAV_STACK && n_prims > 0;   // LDS stack: (depth + 1) KiB per workgroup
-    const bool traverse = trav_ok && ((rq->flags & RT_FLAG_BVH_TRAVERSE) || n_prims > TRAVERSE_MIN_PRIMS);
+    // (the linear engines test every triangle's box per segment: meshes switch to the tree much earlier)
+    const bool traverse = trav_ok && ((rq->flags & RT_FLAG_BVH_TRAVERSE) || n_prims > TRAVERSE_MIN_PRIMS ||
+                                      sc->n_tri > TRAVERSE_MIN_TRIS);
     const bool streamed = !traverse && sc->n_sph_pad > RESIDENT_MAX;
     p.chunk = traverse ? 0 : (streamed ? STREAM_CHUNK : sc->n_sph_pad);
     p.n_chunks = p.chunk ? (sc->n_sph_pad + p.chunk - 1) / p.chunk : 0;
