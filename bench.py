@@ -223,7 +223,8 @@ def main():
                 "mprimary_per_s": prim / elapsed / 1e6,
                 "segments_per_primary": segs / prim,
                 "engine": ["linear scan, scene resident in LDS", "linear scan, scene streamed through LDS",
-                           "per-lane traversal of the reference BVH"][st.engine],
+                           "per-lane traversal of the reference BVH (exact nodes)",
+                           "per-lane traversal of the reference BVH (quantised nodes, exact leaf validation)"][st.engine],
                 "flags": args.flags,
                 "pcie_inclusive": pcie,
                 "broad_candidates_per_segment": float(st.broad_candidates) / max(float(st.ray_segments), 1.0),

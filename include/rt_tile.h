@@ -98,7 +98,12 @@ enum {
      * scenes up to 512 primitives, per-lane traversal of the reference BVH above that.  Both give the
      * reference's result bit for bit; these force one or the other (A/B runs, tests). */
     RT_FLAG_BVH_TRAVERSE = 1u << 4,
-    RT_FLAG_LINEAR_SCAN = 1u << 5
+    RT_FLAG_LINEAR_SCAN = 1u << 5,
+    /* Traversal node format.  Default: the exact 64-byte nodes up to RT_QNODES_MIN_PRIMS primitives, the
+     * 32-byte conservatively quantised nodes (exact validation at the leaves) above that.  Identical images;
+     * these force one or the other (A/B runs, tests). */
+    RT_FLAG_EXACT_NODES = 1u << 6,
+    RT_FLAG_QUANT_NODES = 1u << 7
 };
 
 typedef struct rt_tile_request {
@@ -134,7 +139,8 @@ typedef struct rt_tile_stats {
     float d2h_ms;               /* RGB8 strip download (0 for device output)                  */
     uint32_t n_launches;        /* kernel launches issued by this call                        */
     uint32_t engine;            /* closest-hit engine of the last launch: 0 linear scan (scene resident
-                                   in LDS), 1 linear scan (scene streamed through LDS), 2 BVH traversal */
+                                   in LDS), 1 linear scan (scene streamed through LDS), 2 BVH traversal (exact nodes),
+                                   3 BVH traversal (quantised nodes + exact leaf validation) */
     uint32_t broad_form;        /* linear engines: 0 = oc form, 1 = expanded form   */
 } rt_tile_stats;
 

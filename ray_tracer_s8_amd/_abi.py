@@ -29,6 +29,8 @@ RT_FLAG_OC_BROAD_PHASE = 4
 RT_FLAG_FULL_CHAIN = 8
 RT_FLAG_BVH_TRAVERSE = 16
 RT_FLAG_LINEAR_SCAN = 32
+RT_FLAG_EXACT_NODES = 64
+RT_FLAG_QUANT_NODES = 128
 RT_MAX_BOUNCES = 62
 
 # numpy dtypes with the exact layout of rt_sphere / rt_triangle (no padding)

@@ -54,6 +54,8 @@ constexpr size_t LDS_LIMIT = 160 * 1024 - 1024;   // dynamic LDS budget; 1 KiB l
 constexpr uint32_t RESIDENT_MAX = rtk::CHUNK;   // spheres kept wholly in LDS
 constexpr uint32_t STREAM_CHUNK = 2048;         // chunk size when streaming through LDS
 constexpr uint32_t TRAVERSE_MIN_TRIS = 64;      // ... or above this many triangles
+constexpr uint32_t RT_QNODES_MIN_PRIMS = 4096;   // from here up, and below this leaf density, the traversal walks the
+constexpr float RT_QNODES_MAX_DENSITY = 2.0f;    // 32-byte quantised nodes (measured, tools/crossover_q.py)
 constexpr uint32_t TRAVERSE_MIN_PRIMS = 512;    // above this many primitives the BVH-traversal engine is the default (measured crossover, tools/crossover.py)
 
 }  // namespace
@@ -71,6 +73,11 @@ struct rt_scene {
     float4* d_tri_box = nullptr;
     float4* d_bvh = nullptr;       // rtbvh::FlatNode[]
     float4* d_trav = nullptr;      // rtbvh::TravNode[]
+    uint4* d_travq = nullptr;      // rtbvh::QNode[] (quantised twin)
+    float4* d_geom_r = nullptr;    // (cx,cy,cz,radius)
+    rtbvh::QGrid grid;
+    float leaf_density = 0.f;      // sum of primitive box areas / scene box area (node-format heuristic)
+    bool quant_ok = false;         // quantised walk usable and worthwhile (grid step small against the primitives)
     uint32_t root_ref = 0, bvh_depth = 0;
     uint32_t* d_leaf_of = nullptr;
     float bvh_build_ms = 0.f;
@@ -208,6 +215,13 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     p.tri_box = sc->d_tri_box;
     p.bvh_nodes = sc->d_bvh;
     p.trav = sc->d_trav;
+    p.travq = sc->d_travq;
+    p.geom_r = sc->d_geom_r;
+    for (int i = 0; i < 3; i++) {
+        p.q_base[i] = sc->grid.base[i];
+        p.q_step[i] = sc->grid.step[i];
+        p.q_rstep[i] = 1.0f / sc->grid.step[i];
+    }
     p.root_ref = sc->root_ref;
     p.leaf_of = sc->d_leaf_of;
     p.n_strips = n;
@@ -235,8 +249,14 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
 
     // persistent grid: as many workgroups as the chip holds at this LDS/VGPR budget
     int per_cu = 0;
+    // node format: the halved gather footprint pays once the 64-byte node array is far larger than the per-CU
+    // caches and the rays reach few leaves (c5: +24 %); small or dense scenes are bound by the leaf tests, where
+    // the exact-node kernel's 5 waves/SIMD win (c3: +3 %, dense fields: +10 %).  tools/crossover_q.py, DESIGN.md 4.7
+    const bool qnodes = traverse && sc->quant_ok && !(rq->flags & RT_FLAG_EXACT_NODES) &&
+                        ((rq->flags & RT_FLAG_QUANT_NODES) ||
+                         (n_prims >= RT_QNODES_MIN_PRIMS && sc->leaf_density < RT_QNODES_MAX_DENSITY));
     void (*kern)(rtk::KParams) =
-        traverse ? rtk::rt_tile_kernel<2, false>
+        traverse ? (qnodes ? rtk::rt_tile_kernel<3, false> : rtk::rt_tile_kernel<2, false>)
                  : streamed ? (expanded ? rtk::rt_tile_kernel<1, true> : rtk::rt_tile_kernel<1, false>)
                             : (expanded ? rtk::rt_tile_kernel<0, true> : rtk::rt_tile_kernel<0, false>);
     HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, rtk::BLOCK, lds));
@@ -250,7 +270,7 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     if (rc) return rc;
     HIPCHK(hipMemsetAsync(p.queue, 0, sizeof(unsigned long long), stream));
     HIPCHK(hipEventRecord(ev.a, stream));
-    sc->last_engine = traverse ? 2u : (streamed ? 1u : 0u);
+    sc->last_engine = traverse ? (qnodes ? 3u : 2u) : (streamed ? 1u : 0u);
     sc->last_form = expanded ? 1u : 0u;
     hipLaunchKernelGGL(kern, grid, block, lds, stream, p);
     HIPCHK(hipGetLastError());
@@ -382,6 +402,8 @@ static int ensure_ctx(DeviceCtx* c) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
     HIPCHK(hipFuncSetAttribute((const void*)rtk::rt_tile_kernel<2, false>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
+    HIPCHK(hipFuncSetAttribute((const void*)rtk::rt_tile_kernel<3, false>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
     hipStream_t st = nullptr;
     HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     c->stream = st;
@@ -511,6 +533,45 @@ RT_API int rt_scene_create(int device, const rt_sphere* sp, uint32_t ns, const r
     sc->root_ref = bvh.root_ref;
     sc->bvh_depth = bvh.depth;
     if (bvh.trav.empty()) bvh.trav.push_back(rtbvh::TravNode{});
+    sc->grid = bvh.grid;
+    if (bvh.travq.empty()) bvh.travq.push_back(rtbvh::QNode{});
+    {
+        // worthwhile only if the grid step is small against the primitives (else the rounded boxes admit crowds of
+        // false leaves): median primitive box edge >= 8 steps on every axis
+        bool ok = bvh.grid.ok && np > 1;
+        if (ok) {
+            std::vector<float> edge(np);
+            for (uint32_t i = 0; i < np; i++) {
+                float e = INFINITY;
+                for (int a3 = 0; a3 < 3; a3++)
+                    e = fminf(e, (boxes[i].hi[a3] - boxes[i].lo[a3]) / bvh.grid.step[a3]);
+                edge[i] = e;
+            }
+            std::nth_element(edge.begin(), edge.begin() + np / 2, edge.end());
+            ok = edge[np / 2] >= 8.0f;
+        }
+        sc->quant_ok = ok;
+        // leaf density = sum of primitive box areas / area of the scene box ~ leaves a random ray reaches; above ~2
+        // the walk is bound by the exact leaf tests, where the lighter exact-node kernel (5 waves/SIMD) wins
+        double area = 0.0, root = 0.0;
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (uint32_t i = 0; i < np; i++) {
+            const double ex = (double)boxes[i].hi[0] - boxes[i].lo[0], ey = (double)boxes[i].hi[1] - boxes[i].lo[1],
+                         ez = (double)boxes[i].hi[2] - boxes[i].lo[2];
+            area += ex * ey + ey * ez + ez * ex;
+            for (int a3 = 0; a3 < 3; a3++) {
+                lo[a3] = fminf(lo[a3], boxes[i].lo[a3]);
+                hi[a3] = fmaxf(hi[a3], boxes[i].hi[a3]);
+            }
+        }
+        if (np) {
+            const double ex = (double)hi[0] - lo[0], ey = (double)hi[1] - lo[1], ez = (double)hi[2] - lo[2];
+            root = ex * ey + ey * ez + ez * ex;
+        }
+        sc->leaf_density = root > 0.0 ? (float)(area / root) : INFINITY;
+    }
+    std::vector<float4> geom_r(ns ? ns : 1);
+    for (uint32_t i = 0; i < ns; i++) geom_r[i] = make_float4(sp[i].cx, sp[i].cy, sp[i].cz, sp[i].radius);
     auto cleanup = [&](int code) {
         rt_scene_destroy(sc);
         return code;
@@ -538,6 +599,8 @@ RT_API int rt_scene_create(int device, const rt_sphere* sp, uint32_t ns, const r
     SC_CHK(hipMalloc(&sc->d_bvh, bvh.nodes.size() * sizeof(rtbvh::FlatNode)));
     SC_CHK(hipMalloc(&sc->d_leaf_of, bvh.leaf_of.size() * sizeof(uint32_t)));
     SC_CHK(hipMalloc(&sc->d_trav, bvh.trav.size() * sizeof(rtbvh::TravNode)));
+    SC_CHK(hipMalloc(&sc->d_travq, bvh.travq.size() * sizeof(rtbvh::QNode)));
+    SC_CHK(hipMalloc(&sc->d_geom_r, geom_r.size() * sizeof(float4)));
     SC_CHK(hipMalloc(&sc->d_counters, COUNTER_WORDS * sizeof(unsigned long long)));
     SC_CHK(hipEventRecord(e0, ctx->stream));
     SC_CHK(hipMemcpyAsync(sc->d_geom, geom.data(), geom.size() * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
@@ -551,6 +614,10 @@ RT_API int rt_scene_create(int device, const rt_sphere* sp, uint32_t ns, const r
     SC_CHK(hipMemcpyAsync(sc->d_tri_box, tri_box.data(), tri_box.size() * sizeof(float4), hipMemcpyHostToDevice,
                           ctx->stream));
     SC_CHK(hipMemcpyAsync(sc->d_bvh, bvh.nodes.data(), bvh.nodes.size() * sizeof(rtbvh::FlatNode), hipMemcpyHostToDevice,
+                          ctx->stream));
+    SC_CHK(hipMemcpyAsync(sc->d_travq, bvh.travq.data(), bvh.travq.size() * sizeof(rtbvh::QNode), hipMemcpyHostToDevice,
+                          ctx->stream));
+    SC_CHK(hipMemcpyAsync(sc->d_geom_r, geom_r.data(), geom_r.size() * sizeof(float4), hipMemcpyHostToDevice,
                           ctx->stream));
     SC_CHK(hipMemcpyAsync(sc->d_trav, bvh.trav.data(), bvh.trav.size() * sizeof(rtbvh::TravNode), hipMemcpyHostToDevice,
                           ctx->stream));
@@ -588,6 +655,8 @@ RT_API void rt_scene_destroy(rt_scene* sc) {
     (void)hipFree(sc->d_tri_box);
     (void)hipFree(sc->d_bvh);
     (void)hipFree(sc->d_trav);
+    (void)hipFree(sc->d_travq);
+    (void)hipFree(sc->d_geom_r);
     (void)hipFree(sc->d_leaf_of);
     (void)hipFree(sc->d_counters);
     (void)hipFree(sc->d_out);

@@ -48,12 +48,27 @@ struct TravNode {
     uint32_t pad1;
 };
 
+// Quantised traversal node (32 bytes = two uint4): the same topology as TravNode, child boxes rounded OUTWARDS onto
+// a 16-bit grid over the scene box (coordinate = base + q*step) with at least one whole grid unit of slack.  Only a conservative pre-filter: the
+// kernel validates every leaf it reaches with the exact box.
+struct QNode {
+    uint16_t l_lo[3], l_hi[3], r_lo[3], r_hi[3];
+    uint32_t left, right;
+};
+
+struct QGrid {
+    float base[3] = {0.f, 0.f, 0.f}, step[3] = {1.f, 1.f, 1.f};
+    bool ok = false;                 // false: degenerate / non-finite scene box, use the exact nodes
+};
+
 struct FlatBVH {
     std::vector<FlatNode> nodes;
     std::vector<uint32_t> leaf_of;   // primitive index -> node index (= DFS rank)
     std::vector<TravNode> trav;      // internal nodes, root first (empty when the root is a leaf)
     uint32_t root_ref = 0;           // reference of the root (LEAF_BIT | 0 for a single primitive)
     uint32_t depth = 0;              // edges on the longest root-to-leaf path
+    std::vector<QNode> travq;        // quantised twin of trav
+    QGrid grid;
 };
 
 inline Box empty_box() {
@@ -230,6 +245,53 @@ inline FlatBVH build(const std::vector<Box>& prim) {
         t.pad0 = t.pad1 = 0;
     }
     out.root_ref = ref_of(0);
+
+    // ---- quantised twin.  Grid over the union of the root's child boxes, 4 units of margin below and 11 above.
+    // The device never decodes a coordinate: it evaluates the slab test in grid units (rt_kernel.hip.h), with
+    // < 0.15 unit of rounding against the >= 1 unit of outward slack given here.
+    if (!out.trav.empty()) {
+        QGrid g;
+        g.ok = true;
+        const TravNode& r0 = out.trav[0];
+        for (int a = 0; a < 3; a++) {
+            const float lo = fminf(r0.l_lo[a], r0.r_lo[a]), hi = fmaxf(r0.l_hi[a], r0.r_hi[a]);
+            if (!(std::isfinite(lo) && std::isfinite(hi)) || !(hi >= lo)) g.ok = false;
+            const double ext = (double)hi - (double)lo;
+            float st = (float)(ext / 65520.0);                // 16 units of head-room: no box is ever clamped
+            if (!(st > 0.f)) st = 1e-30f;                     // flat scene along this axis
+            g.step[a] = st;
+            g.base[a] = (float)((double)lo - 4.0 * (double)st);
+            if (!std::isfinite(st) || !std::isfinite(g.base[a])) g.ok = false;
+        }
+        if (g.ok) {
+            out.travq.resize(out.trav.size());
+            // grid coordinate with at least one whole unit of outward slack, in exact (double) arithmetic:
+            // base + q_lo*step <= v - step  and  base + q_hi*step >= v + step
+            auto q_lo = [&](float v, int a, bool& ok) {
+                const double q = std::floor(((double)v - (double)g.base[a]) / (double)g.step[a]) - 1.0;
+                if (!(q >= 0.0 && q <= 65535.0)) ok = false;
+                return (uint16_t)(q >= 0.0 && q <= 65535.0 ? q : 0.0);
+            };
+            auto q_hi = [&](float v, int a, bool& ok) {
+                const double q = std::ceil(((double)v - (double)g.base[a]) / (double)g.step[a]) + 1.0;
+                if (!(q >= 0.0 && q <= 65535.0)) ok = false;
+                return (uint16_t)(q >= 0.0 && q <= 65535.0 ? q : 65535.0);
+            };
+            for (size_t n = 0; n < out.trav.size() && g.ok; n++) {
+                const TravNode& tn = out.trav[n];
+                QNode& qn = out.travq[n];
+                for (int a = 0; a < 3; a++) {
+                    qn.l_lo[a] = q_lo(tn.l_lo[a], a, g.ok);
+                    qn.l_hi[a] = q_hi(tn.l_hi[a], a, g.ok);
+                    qn.r_lo[a] = q_lo(tn.r_lo[a], a, g.ok);
+                    qn.r_hi[a] = q_hi(tn.r_hi[a], a, g.ok);
+                }
+                qn.left = tn.left;
+                qn.right = tn.right;
+            }
+        }
+        out.grid = g;
+    }
     return out;
 }
 

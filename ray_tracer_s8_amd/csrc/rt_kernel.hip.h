@@ -41,6 +41,9 @@ constexpr int BLOCK = 256;       // 4 waves
 #ifndef RT_MINWAVES_TRAV
 #define RT_MINWAVES_TRAV 5
 #endif
+#ifndef RT_MINWAVES_QTRAV       // quantised-node traversal: 114 VGPRs; 5 waves/SIMD spills 41 of them (slower)
+#define RT_MINWAVES_QTRAV 4
+#endif
 constexpr int MAXC = RT_MAXC;    // candidate list slots per lane (per chunk)
 constexpr int CHUNK = 2048;      // max spheres per LDS chunk (32 KiB): list entries carry an 8-bit group index
 constexpr int UNROLL = 8;        // broad-phase unroll; chunk sizes are padded to this
@@ -96,6 +99,9 @@ struct KParams {
     const float* tri;            // [n_tri*9] a,b,c
     const float4* tri_box;       // [2*n_tri] Triangle::aabb (lo, hi) as the BVH sees it
     const float4* trav;          // [4*n_internal] rtbvh::TravNode: (l_lo, left)(l_hi, right)(r_lo,-)(r_hi,-)
+    const uint4* travq;          // [2*n_internal] rtbvh::QNode: 12 x u16 grid coordinates, left, right
+    const float4* geom_r;        // [n_sph] (cx,cy,cz, radius): exact Sphere::aabb on the fly for leaf validation
+    float q_base[3], q_step[3], q_rstep[3];   // grid: coordinate = q_base + q * q_step; q_rstep = 1 / q_step
     uint32_t root_ref;           // root reference (LEAF_BIT | prim when the tree is a single leaf)
     uint32_t pad_kp;
     const float4* bvh_nodes;     // [2*n_nodes]: (lo.xyz, parent as bits) (hi.xyz, -) — rt_bvh.h FlatNode
@@ -370,6 +376,18 @@ __device__ __forceinline__ void consider(Hit& h, int idx, V3 o, V3 d, float t, c
     h.p = p;
 }
 
+// index-order first minimum over the primitives that satisfy `admitted` (evaluated only for an improving hit)
+template <class Pred>
+__device__ __forceinline__ void consider_if(Hit& h, int idx, V3 o, V3 d, float t, Pred admitted) {
+    V3 p = o + t * d;
+    float dist = vlength(p - o);
+    if (!(h.idx < 0 || h.dist > dist)) return;
+    if (!admitted()) return;
+    h.idx = idx;
+    h.dist = dist;
+    h.p = p;
+}
+
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
@@ -409,11 +427,14 @@ __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_el
 
 // ------------------------------------------------------------------ the kernel
 // ISECT selects the closest-hit engine: 0 = linear scan, scene resident in LDS; 1 = linear scan, scene streamed
-// through LDS in chunks; 2 = per-lane traversal of the reference BVH (large scenes: O(log N) per ray).
+// through LDS in chunks; 2 = per-lane traversal of the reference BVH (exact 64-byte nodes); 3 = the same walk over
+// 32-byte nodes whose boxes are rounded outwards onto a 16-bit grid, every reached leaf being validated with the
+// reference's exact own-leaf AABB test.
 template <int ISECT, bool EXPANDED>
-__global__ __launch_bounds__(BLOCK, ISECT == 2 ? RT_MINWAVES_TRAV : RT_MINWAVES) void rt_tile_kernel(const KParams p) {
+__global__ __launch_bounds__(BLOCK, ISECT == 3 ? RT_MINWAVES_QTRAV : ISECT == 2 ? RT_MINWAVES_TRAV : RT_MINWAVES) void rt_tile_kernel(const KParams p) {
     constexpr bool STREAMED = (ISECT == 1);
-    constexpr bool TRAVERSE = (ISECT == 2);
+    constexpr bool TRAVERSE = (ISECT >= 2);
+    constexpr bool QNODES = (ISECT == 3);            // traversal over 32-byte conservatively quantised nodes
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     float4* lgeom = reinterpret_cast<float4*>(lds_raw);          // pair layout, see KParams::geom_pk / geom_px
     const float* lgeomf = reinterpret_cast<const float*>(lds_raw);
@@ -470,6 +491,8 @@ __global__ __launch_bounds__(BLOCK, ISECT == 2 ? RT_MINWAVES_TRAV : RT_MINWAVES)
     V3 td = mk(0, 0, 0);
     bool in_trav = false;
     uint32_t t_ref = 0, t_sp = 0, t_cnt = 0;
+    V3 ig = mk(0, 0, 0), cq = mk(0, 0, 0);   // QNODES: the ray in grid units, t(q) = q * ig + cq
+    bool qfin = false;                       // QNODES: this lane may use the quantised boxes
     uint32_t* lc32 = reinterpret_cast<uint32_t*>(lds_raw + p.lds_cand_off);     // TRAVERSE: leaf candidates (u32)
     uint32_t* lstack = reinterpret_cast<uint32_t*>(lds_raw + p.lds_stack_off);   // TRAVERSE: per-lane stack
 
@@ -589,6 +612,16 @@ __global__ __launch_bounds__(BLOCK, ISECT == 2 ? RT_MINWAVES_TRAV : RT_MINWAVES)
             aux = ray_aux(d, (p.flags & 8u) != 0);
             td = 2.0f * d;                                   // (2f32 * ray.direction), sphere.rs:44
             n_seg++;
+            if (QNODES) {
+                // the ray in grid units: t(q) = q * ig + cq with ig = step * inv, cq = -((o - base) / step) * ig
+                const V3 og = mk((o.x - p.q_base[0]) * p.q_rstep[0], (o.y - p.q_base[1]) * p.q_rstep[1], (o.z - p.q_base[2]) * p.q_rstep[2]);
+                ig = mk(p.q_step[0] * aux.inv.x, p.q_step[1] * aux.inv.y, p.q_step[2] * aux.inv.z);
+                cq = mk(-(og.x * ig.x), -(og.y * ig.y), -(og.z * ig.z));
+                const float big = 0x1p100f, tiny = 0x1p-60f;
+                const float ax = __builtin_fabsf(ig.x), ay = __builtin_fabsf(ig.y), az = __builtin_fabsf(ig.z);
+                qfin = aux.finite && ax < big && ay < big && az < big && ax > tiny && ay > tiny && az > tiny &&
+                       __builtin_fabsf(og.x) < 0x1p18f && __builtin_fabsf(og.y) < 0x1p18f && __builtin_fabsf(og.z) < 0x1p18f;
+            }
             if (TRAVERSE) {
                 t_ref = p.root_ref;
                 t_sp = 0;
@@ -609,13 +642,32 @@ __global__ __launch_bounds__(BLOCK, ISECT == 2 ? RT_MINWAVES_TRAV : RT_MINWAVES)
                     LCOUNT(6);
                     const uint32_t prim = lc32[i * BLOCK + tid];
                     float t;
+                    // The quantised walk only over-approximates BVH::traverse, so a leaf it delivers counts iff
+                    // the reference would have reached it = its own exact box passes (leaf-box lemma, bvh_reaches;
+                    // Sphere::aabb = c -+ r).  The filter is a pure predicate of (ray, primitive), so it is applied
+                    // lazily: only to a hit that would replace the running closest one.  (A lane without a finite
+                    // inverse direction walked the exact nodes: nothing to validate.)
                     if (prim < p.n_sph) {
                         const float4 g = p.geom[prim];
-                        if (exact_sphere(o, td, mk(g.x, g.y, g.z), g.w, p.t_min, p.t_max, t))
-                            consider<0>(h, (int)prim, o, d, t, aux, p.bvh_nodes, p.leaf_of);
+                        if (exact_sphere(o, td, mk(g.x, g.y, g.z), g.w, p.t_min, p.t_max, t)) {
+                            if (QNODES)
+                                consider_if(h, (int)prim, o, d, t, [&]() {
+                                    if (!qfin || (p.n_sph + p.n_tri) == 1) return true;
+                                    const float4 s = p.geom_r[prim];
+                                    return intersects_aabb_finite(o, aux, make_float4(s.x - s.w, s.y - s.w, s.z - s.w, 0.f),
+                                                                  make_float4(s.x + s.w, s.y + s.w, s.z + s.w, 0.f));
+                                });
+                            else
+                                consider<0>(h, (int)prim, o, d, t, aux, p.bvh_nodes, p.leaf_of);
+                        }
                     } else {
-                        if (exact_triangle(o, d, p.tri + 9 * (size_t)(prim - p.n_sph), p.t_min, p.t_max, t))
-                            consider<0>(h, (int)prim, o, d, t, aux, p.bvh_nodes, p.leaf_of);
+                        if (exact_triangle(o, d, p.tri + 9 * (size_t)(prim - p.n_sph), p.t_min, p.t_max, t)) {
+                            if (QNODES)
+                                consider_if(h, (int)prim, o, d, t,
+                                            [&]() { return !qfin || bvh_reaches(p.bvh_nodes, p.leaf_of[prim], o, aux); });
+                            else
+                                consider<0>(h, (int)prim, o, d, t, aux, p.bvh_nodes, p.leaf_of);
+                        }
                     }
                 }
                 t_cnt = 0;
@@ -624,7 +676,11 @@ __global__ __launch_bounds__(BLOCK, ISECT == 2 ? RT_MINWAVES_TRAV : RT_MINWAVES)
                 const uint32_t walking = (uint32_t)__builtin_popcountll(__ballot(in_trav));
                 const uint32_t live = (uint32_t)__builtin_popcountll(__ballot(true));
                 if (walking == 0 || (walking * 8 <= live * RT_REFILL_EIGHTHS && walking < live)) break;
+#ifdef RT_ROLL_STEPS
+#pragma clang loop unroll(disable)
+#else
 #pragma unroll
+#endif
                 for (int rep = 0; rep < RT_STEPS_PER_CHECK; rep++)
                 if (in_trav) {
                     WCOUNT(5);
@@ -640,17 +696,55 @@ __global__ __launch_bounds__(BLOCK, ISECT == 2 ? RT_MINWAVES_TRAV : RT_MINWAVES)
                             t_ref = lstack[--t_sp * BLOCK + tid];
                         }
                     } else {
-                        const float4* __restrict__ nd = p.trav + 4 * (size_t)t_ref;
-                        const float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
                         bool hl, hr;
-                        if (aux.finite) {                    // (RT_FLAG_FULL_CHAIN also forces the crate's literal form)
-                            hl = intersects_aabb_finite(o, aux, n0, n1);
-                            hr = intersects_aabb_finite(o, aux, n2, n3);
+                        uint32_t cl, cr;
+                        if (QNODES) {
+                            uint4 qa = p.travq[2 * (size_t)t_ref], qb = p.travq[2 * (size_t)t_ref + 1];
+                            asm volatile("" : "+v"(qb.x), "+v"(qb.y), "+v"(qb.z), "+v"(qb.w));   // keep the two 16-byte loads whole
+                            cl = qb.z;
+                            cr = qb.w;
+                            if (qfin) {
+                                // slab test in grid units: t = fma(q, ig, cq), the same real value as
+                                // ((base + q*step) - o) * inv up to < 0.15 grid unit of rounding; the boxes carry >= 1 grid
+                                // unit of outward slack: conservative, exactness restored at the leaves
+#define RT_Q(word, hi16) ((float)((hi16) ? ((word) >> 16) : ((word) & 0xffffu)))
+                                const float lx0 = __builtin_fmaf(RT_Q(qa.x, 0), ig.x, cq.x), lx1 = __builtin_fmaf(RT_Q(qa.y, 1), ig.x, cq.x);
+                                const float ly0 = __builtin_fmaf(RT_Q(qa.x, 1), ig.y, cq.y), ly1 = __builtin_fmaf(RT_Q(qa.z, 0), ig.y, cq.y);
+                                const float lz0 = __builtin_fmaf(RT_Q(qa.y, 0), ig.z, cq.z), lz1 = __builtin_fmaf(RT_Q(qa.z, 1), ig.z, cq.z);
+                                const float rx0 = __builtin_fmaf(RT_Q(qa.w, 0), ig.x, cq.x), rx1 = __builtin_fmaf(RT_Q(qb.x, 1), ig.x, cq.x);
+                                const float ry0 = __builtin_fmaf(RT_Q(qa.w, 1), ig.y, cq.y), ry1 = __builtin_fmaf(RT_Q(qb.y, 0), ig.y, cq.y);
+                                const float rz0 = __builtin_fmaf(RT_Q(qb.x, 0), ig.z, cq.z), rz1 = __builtin_fmaf(RT_Q(qb.y, 1), ig.z, cq.z);
+#undef RT_Q
+                                const float lmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(lx0, lx1), __builtin_fminf(ly0, ly1)),
+                                                                   __builtin_fminf(lz0, lz1));
+                                const float lmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(lx0, lx1), __builtin_fmaxf(ly0, ly1)),
+                                                                   __builtin_fmaxf(lz0, lz1));
+                                const float rmin_ = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(rx0, rx1), __builtin_fminf(ry0, ry1)),
+                                                                    __builtin_fminf(rz0, rz1));
+                                const float rmax_ = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(rx0, rx1), __builtin_fmaxf(ry0, ry1)),
+                                                                    __builtin_fmaxf(rz0, rz1));
+                                hl = __builtin_fmaxf(lmin, 0.0f) <= lmax;
+                                hr = __builtin_fmaxf(rmin_, 0.0f) <= rmax_;
+                            } else {
+                                // +-0 direction component (inverse = +-inf): the monotonicity argument does not hold, so
+                                // this lane walks the exact nodes with the crate's literal test; its leaves need no validation
+                                const float4* __restrict__ nd = p.trav + 4 * (size_t)t_ref;
+                                hl = intersects_aabb(o, aux, nd[0], nd[1]);
+                                hr = intersects_aabb(o, aux, nd[2], nd[3]);
+                            }
                         } else {
-                            hl = intersects_aabb(o, aux, n0, n1);
-                            hr = intersects_aabb(o, aux, n2, n3);
+                            const float4* __restrict__ nd = p.trav + 4 * (size_t)t_ref;
+                            const float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
+                            if (aux.finite) {                    // (RT_FLAG_FULL_CHAIN also forces the crate's literal form)
+                                hl = intersects_aabb_finite(o, aux, n0, n1);
+                                hr = intersects_aabb_finite(o, aux, n2, n3);
+                            } else {
+                                hl = intersects_aabb(o, aux, n0, n1);
+                                hr = intersects_aabb(o, aux, n2, n3);
+                            }
+                            cl = __float_as_uint(n0.w);
+                            cr = __float_as_uint(n1.w);
                         }
-                        const uint32_t cl = __float_as_uint(n0.w), cr = __float_as_uint(n1.w);
                         if (hl) {
                             if (hr) lstack[t_sp++ * BLOCK + tid] = cr;   // right subtree after the whole left subtree
                             t_ref = cl;

@@ -65,10 +65,15 @@ def test_c3_full_4k_bit_exact_and_filter_is_conservative(ndev, oracle):
     # property: broad phase off (exact root computation against every sphere) == broad phase on
     rgb_x, _, st_x = _frame_gpu(sph, rq, flags=rt.RT_FLAG_EXACT_SCAN)
     assert np.array_equal(rgb_x, rgb) and st_x.ray_segments == st.ray_segments
-    # the two broad-phase forms (8-op expanded = default for this scene, 11-op oc) agree at full size
-    rgb_o, _, st_o = _frame_gpu(sph, rq, flags=4)
+    # default engine here = traversal over exact nodes; the quantised nodes give the same frame
+    rgb_e, _, st_e = _frame_gpu(sph, rq, flags=128)
+    assert st.engine == 2 and st_e.engine == 3
+    assert np.array_equal(rgb_e, rgb) and st_e.ray_segments == st.ray_segments
+    # the two broad-phase forms of the linear engine (8-op expanded, 11-op oc) agree at full size
+    rgb_o, _, st_o = _frame_gpu(sph, rq, flags=4 | 32)
     assert np.array_equal(rgb_o, rgb) and st_o.ray_segments == st.ray_segments
-    assert st.broad_candidates >= st_o.broad_candidates
+    rgb_x2, _, st_x2 = _frame_gpu(sph, rq, flags=32)
+    assert np.array_equal(rgb_x2, rgb) and st_x2.broad_candidates >= st_o.broad_candidates
     # plain linear-scan semantics against the oracle's linear back-end, also at full size
     lin, _, st_l = _frame_gpu(sph, rq, flags=rt.RT_FLAG_NO_BVH_CULL)
     ref_l, _, info_l = _frame_oracle(oracle, sph, rq, backend=0)
@@ -115,10 +120,15 @@ def test_c5_65536_spheres_streamed_full_frame(ndev, oracle):
     assert st.exact_fallbacks <= st.ray_segments // 1000
     # default engine for 65 536 spheres is the BVH traversal; the LDS-streamed linear scan agrees on a strip,
     # with the leaf-box shortcut of its BVH validation and with the whole chain walked (RT_FLAG_FULL_CHAIN)
+    # (at this size over the 32-byte quantised nodes; the exact 64-byte nodes give the same strip)
+    assert st.engine == 3
     r0 = rq.copy()
     r0.division_no, r0.flags = 11, 32
     with rt.Scene(0, rt.World(sph)) as sc:
         lin_strip, _, st_lin = sc.render_tile(r0)
+        r0.flags = 64
+        ex_strip, _, st_ex = sc.render_tile(r0)
+    assert st_ex.engine == 2 and np.array_equal(ex_strip, lin_strip)
     strip0 = rgb.size // rq.divisions
     assert np.array_equal(lin_strip, rgb[11 * strip0:12 * strip0])
     r1 = rq.copy()

@@ -10,7 +10,9 @@ pytestmark = pytest.mark.gpu
 import ray_tracer_s8_amd as rt
 from ray_tracer_s8_amd import _abi
 
-ENGINE_FLAGS = [0, _abi.RT_FLAG_LINEAR_SCAN, _abi.RT_FLAG_BVH_TRAVERSE, _abi.RT_FLAG_LINEAR_SCAN | _abi.RT_FLAG_OC_BROAD_PHASE,
+ENGINE_FLAGS = [0, _abi.RT_FLAG_LINEAR_SCAN, _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_QUANT_NODES,
+                _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_EXACT_NODES,
+                _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_FULL_CHAIN, _abi.RT_FLAG_LINEAR_SCAN | _abi.RT_FLAG_OC_BROAD_PHASE,
                 _abi.RT_FLAG_NO_BVH_CULL, _abi.RT_FLAG_EXACT_SCAN, _abi.RT_FLAG_LINEAR_SCAN | _abi.RT_FLAG_FULL_CHAIN]
 
 

@@ -191,9 +191,12 @@ def test_bvh_traversal_engine(ndev, oracle, scene):
     else:
         sph = scenes.rand65536(n=9000)
         rq = _abi.default_request(width=128, height=80, divisions=1, spp=2, max_bounces=5, seed=99)
-    a = _compare(oracle, rq, sph, tri, flags=_abi.RT_FLAG_BVH_TRAVERSE)
+    a = _compare(oracle, rq, sph, tri, flags=_abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_QUANT_NODES)
+    c = _compare(oracle, rq, sph, tri, flags=_abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_EXACT_NODES)
     b = _compare(oracle, rq, sph, tri, flags=_abi.RT_FLAG_LINEAR_SCAN)
-    assert a.ray_segments == b.ray_segments
+    assert a.ray_segments == b.ray_segments == c.ray_segments
+    assert c.engine == 2 and b.engine in (0, 1)
+    assert a.broad_candidates >= c.broad_candidates                    # rounded boxes can only admit more leaves
 
 
 def test_strips_equal_whole_frame(ndev):
