@@ -261,6 +261,10 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
                             : (expanded ? rtk::rt_tile_kernel<0, true> : rtk::rt_tile_kernel<0, false>);
     HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, rtk::BLOCK, lds));
     if (per_cu < 1) per_cu = 1;
+    static const bool verbose = getenv("RT_VERBOSE") != nullptr;
+    if (verbose)
+        fprintf(stderr, "[rt] engine %d  lds %zu B  workgroups/CU %d  bvh depth %u  leaf density %.3f  prims %u\n",
+                traverse ? (qnodes ? 3 : 2) : (streamed ? 1 : 0), lds, per_cu, sc->bvh_depth, sc->leaf_density, n_prims);
     uint32_t blocks = (uint32_t)sc->ctx->n_cu * (uint32_t)per_cu;
     const uint32_t useful = (p.n_tiles + 3) / 4;                 // a wave needs at least one tile
     if (blocks > useful) blocks = useful ? useful : 1;

@@ -676,6 +676,11 @@ __global__ __launch_bounds__(BLOCK, ISECT == 3 ? RT_MINWAVES_QTRAV : ISECT == 2 
                 const uint32_t walking = (uint32_t)__builtin_popcountll(__ballot(in_trav));
                 const uint32_t live = (uint32_t)__builtin_popcountll(__ballot(true));
                 if (walking == 0 || (walking * 8 <= live * RT_REFILL_EIGHTHS && walking < live)) break;
+#ifndef RT_FLUSH_INLINE
+                // a lane whose leaf list is full waits at its leaf until this point (keeps the root tests out of the
+                // unrolled step code: one copy instead of RT_STEPS_PER_CHECK; c3 +1 %, 45 % less code)
+                if (in_trav && t_cnt == (uint32_t)MAXL) flush();
+#endif
 #ifdef RT_ROLL_STEPS
 #pragma clang loop unroll(disable)
 #else
@@ -686,7 +691,11 @@ __global__ __launch_bounds__(BLOCK, ISECT == 3 ? RT_MINWAVES_QTRAV : ISECT == 2 
                     WCOUNT(5);
                     LCOUNT(5);
                     if (t_ref & LEAF_BIT) {
+#ifdef RT_FLUSH_INLINE
                         if (t_cnt == (uint32_t)MAXL) flush();
+#else
+                        if (t_cnt == (uint32_t)MAXL) continue;
+#endif
                         lc32[t_cnt * BLOCK + tid] = t_ref & ~LEAF_BIT;
                         t_cnt++;
                         n_cand++;

@@ -12,7 +12,7 @@ rt.init()
 sph, rq = scenes.config(sys.argv[1] if len(sys.argv) > 1 else "c3")
 reqs = []
 for k in range(rq.divisions):
-    r = rq.copy(); r.division_no = k; reqs.append(r)
+    r = rq.copy(); r.division_no = k; r.flags = int(sys.argv[2]) if len(sys.argv) > 2 else 0; reqs.append(r)
 names = ["main-loop iterations", "pixel acquisition body", "camera gen", "UnitDisc loop iters", "broad pass-branch entries",
          "narrow loop iters", "exact hits -> consider", "bvh validation", "shade hit branch", "scatter (UnitSphere)",
          "UnitSphere loop iters", "sky branch", "finish", "path product loop iters", "pixel finalize"]
