@@ -223,6 +223,12 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
         p.q_rstep[i] = 1.0f / sc->grid.step[i];
     }
     p.root_ref = sc->root_ref;
+    {
+        // refill threshold: long walks (large scenes) want finished lanes replaced sooner, short walks amortise the
+        // per-round shading / ray-generation code over more finished lanes (tools/variants_q.sh sweeps)
+        static const int forced = [] { const char* e = getenv("RT_REFILL_EIGHTHS"); return e ? atoi(e) : 0; }();
+        p.refill_eighths = forced > 0 ? (uint32_t)forced : (n_prims >= RT_QNODES_MIN_PRIMS ? 4u : 2u);
+    }
     p.leaf_of = sc->d_leaf_of;
     p.n_strips = n;
     // Tile shape: 64x1 keeps each tile row on whole 64-byte lines of the RGB8 strip (64 px * 3 B = 3 lines),

@@ -103,7 +103,7 @@ struct KParams {
     const float4* geom_r;        // [n_sph] (cx,cy,cz, radius): exact Sphere::aabb on the fly for leaf validation
     float q_base[3], q_step[3], q_rstep[3];   // grid: coordinate = q_base + q * q_step; q_rstep = 1 / q_step
     uint32_t root_ref;           // root reference (LEAF_BIT | prim when the tree is a single leaf)
-    uint32_t pad_kp;
+    uint32_t refill_eighths;     // traversal: finished lanes are refilled once <= this many eighths of the live lanes still walk
     const float4* bvh_nodes;     // [2*n_nodes]: (lo.xyz, parent as bits) (hi.xyz, -) — rt_bvh.h FlatNode
     const uint32_t* leaf_of;     // [n_sph+n_tri] primitive -> leaf node index (= DFS rank)
     unsigned long long* counters;// [0] segments [1] candidates [2] fallbacks
@@ -675,7 +675,7 @@ __global__ __launch_bounds__(BLOCK, ISECT == 3 ? RT_MINWAVES_QTRAV : ISECT == 2 
             for (;;) {
                 const uint32_t walking = (uint32_t)__builtin_popcountll(__ballot(in_trav));
                 const uint32_t live = (uint32_t)__builtin_popcountll(__ballot(true));
-                if (walking == 0 || (walking * 8 <= live * RT_REFILL_EIGHTHS && walking < live)) break;
+                if (walking == 0 || (walking * 8 <= live * p.refill_eighths && walking < live)) break;
 #ifndef RT_FLUSH_INLINE
                 // a lane whose leaf list is full waits at its leaf until this point (keeps the root tests out of the
                 // unrolled step code: one copy instead of RT_STEPS_PER_CHECK; c3 +1 %, 45 % less code)
