@@ -457,3 +457,34 @@ def test_controller_shim_with_gpu_slaves(ndev, oracle):
         assert np.abs(img - ref.reshape(64, 96, 3)).mean() < 6.0
     finally:
         ctl.stop()
+
+
+@pytest.mark.parametrize("flags", [_abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_QUANT_NODES,
+                                   _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_EXACT_NODES])
+def test_quantised_walk_fallback_lanes(ndev, oracle, flags):
+    """Rays the grid form cannot carry walk the exact nodes inside the quantised kernel: (a) a tiny cluster seen from
+    far outside its 16-bit grid (|origin| > 2^18 grid units: every camera ray), (b) axis-parallel directions (aperture 0,
+    a sphere row straight ahead: +-0 direction components after the mirror bounce off flat-facing surfaces)."""
+    g = np.random.default_rng(77)
+    n = 600
+    sph = np.zeros(n, _abi.SPHERE_DTYPE)
+    sph["cx"] = g.uniform(-0.01, 0.01, n)
+    sph["cy"] = g.uniform(-0.01, 0.01, n)
+    sph["cz"] = -3.0 + g.uniform(-0.01, 0.01, n)
+    sph["radius"] = g.uniform(0.0004, 0.0012, n)
+    for c in ("albedo_r", "albedo_g", "albedo_b"):
+        sph[c] = g.uniform(0.2, 0.9, n)
+    sph["roughness"] = g.choice([0.0, 1.0], n)
+    rq = _abi.default_request(width=96, height=96, divisions=1, spp=8, max_bounces=4, seed=5)
+    rq.fov = 0.02                                           # the cluster fills the frame
+    st = _compare(oracle, rq, sph, flags=flags)
+    assert st.ray_segments > rq.width * rq.height * rq.spp     # some paths did bounce
+    # (b) mirror spheres on the optical axis, pinhole camera: reflected rays with exact zero components
+    row = np.zeros(3, _abi.SPHERE_DTYPE)
+    row["cz"] = [-4.0, -9.0, -2000.0]
+    row["radius"] = [1.0, 2.0, 1900.0]
+    row["albedo_r"] = row["albedo_g"] = row["albedo_b"] = 0.9
+    row["roughness"] = 1.0
+    rq2 = _abi.default_request(width=65, height=65, divisions=1, spp=4, max_bounces=6, seed=9)
+    rq2.aperture = 0.0
+    _compare(oracle, rq2, np.concatenate([row, sph]), flags=flags)
