@@ -178,11 +178,13 @@ def main():
         segs, prim = float(c[0].item()), float(c[1].item())
 
     # PCIe-inclusive rate (never `value`): the same frame through the host-buffer entry point
-    # (rt_scene_render_tiles: kernel + one D2H copy per strip into pageable host memory), one pass, N = 1 only
+    # (rt_scene_render_tiles: kernel launches + D2H copies into pageable host memory, the copies of all but
+    # the last quarter of the strips overlapped with the last launch; d2h_ms = the exposed part), N = 1 only
     pcie = None
     if rank == 0 and world == 1:
+        bufs, _, _ = scene.render_tiles(reqs)          # first pass touches the pages of the host buffers
         th0 = time.perf_counter()
-        _, _, st_h = scene.render_tiles(reqs)
+        _, _, st_h = scene.render_tiles(reqs, out=bufs)
         th1 = time.perf_counter()
         pcie = {"ms_per_frame_host_buffers": (th1 - th0) * 1e3, "kernel_ms": st_h.kernel_ms, "d2h_ms": st_h.d2h_ms,
                 "mrays_per_s": float(st_h.ray_segments) / (th1 - th0) / 1e6,

@@ -42,6 +42,7 @@ int fail(int code, const std::string& msg) {
 struct DeviceCtx {
     int dev = -1;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;   // D2H of finished strips while the next launch of the batch runs
     int n_cu = 0;
     std::mutex mu;   // serialises synchronous calls on one device
 };
@@ -414,8 +415,10 @@ static int ensure_ctx(DeviceCtx* c) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
     HIPCHK(hipFuncSetAttribute((const void*)rtk::rt_tile_kernel<3, false>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
-    hipStream_t st = nullptr;
+    hipStream_t st = nullptr, cs = nullptr;
     HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+    c->copy_stream = cs;
     c->stream = st;
     return RT_OK;
 }
@@ -425,6 +428,7 @@ RT_API void rt_shutdown(void) {
     for (DeviceCtx* c : g_ctx) {
         (void)hipSetDevice(c->dev);
         if (c->stream) (void)hipStreamDestroy(c->stream);
+        if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
         delete c;
     }
     g_ctx.clear();
@@ -763,24 +767,40 @@ RT_API int rt_scene_render_tiles(rt_scene* sc, const rt_tile_request* rqs, uint3
         drgb[i] = sc->d_out + need * i;
         df32[i] = (want_f32 && out_f32[i]) ? (void*)(sc->d_outf + need * i) : nullptr;
     }
-    for (uint32_t i0 = 0; i0 < n; i0 += rtk::MAX_BATCH) {
-        uint32_t m = std::min<uint32_t>(rtk::MAX_BATCH, n - i0);
-        rc = launch_batch(sc, rqs + i0, m, drgb.data() + i0, want_f32 ? df32.data() + i0 : nullptr, st);
+    // Launch groups: the last quarter of the strips goes out as its own launch, so that the D2H copies of the strips
+    // before it (copy stream) run under it and only the last group's copies are exposed (d2h_ms = that exposed part).
+    std::vector<std::pair<uint32_t, uint32_t>> groups;    // [first, count)
+    {
+        const uint32_t tail = n >= 4 ? std::max<uint32_t>(1, n / 4) : 0;
+        for (uint32_t i0 = 0; i0 < n - tail; i0 += rtk::MAX_BATCH)
+            groups.emplace_back(i0, std::min<uint32_t>(rtk::MAX_BATCH, n - tail - i0));
+        for (uint32_t i0 = n - tail; i0 < n; i0 += rtk::MAX_BATCH)
+            groups.emplace_back(i0, std::min<uint32_t>(rtk::MAX_BATCH, n - i0));
+    }
+    hipStream_t cs = sc->ctx->copy_stream;
+    std::vector<EvPair> gev(groups.size());
+    for (size_t g = 0; g < groups.size(); g++) {
+        rc = get_events(sc, gev[g]);
         if (rc) return rc;
     }
-    EvPair ev;
-    rc = get_events(sc, ev);
-    if (rc) return rc;
-    HIPCHK(hipEventRecord(ev.a, st));
-    for (uint32_t i = 0; i < n; i++) {
-        HIPCHK(hipMemcpyAsync(out_rgb[i], drgb[i], need, hipMemcpyDeviceToHost, st));
-        if (df32[i]) HIPCHK(hipMemcpyAsync(out_f32[i], df32[i], need * sizeof(float), hipMemcpyDeviceToHost, st));
+    for (size_t g = 0; g < groups.size(); g++) {
+        const uint32_t i0 = groups[g].first, m = groups[g].second;
+        rc = launch_batch(sc, rqs + i0, m, drgb.data() + i0, want_f32 ? df32.data() + i0 : nullptr, st);
+        if (rc) return rc;
+        HIPCHK(hipEventRecord(gev[g].a, st));
     }
-    HIPCHK(hipEventRecord(ev.b, st));
-    HIPCHK(hipEventSynchronize(ev.b));
+    for (size_t g = 0; g < groups.size(); g++) {
+        HIPCHK(hipStreamWaitEvent(cs, gev[g].a, 0));
+        for (uint32_t i = groups[g].first; i < groups[g].first + groups[g].second; i++) {
+            HIPCHK(hipMemcpyAsync(out_rgb[i], drgb[i], need, hipMemcpyDeviceToHost, cs));
+            if (df32[i]) HIPCHK(hipMemcpyAsync(out_f32[i], df32[i], need * sizeof(float), hipMemcpyDeviceToHost, cs));
+        }
+    }
+    HIPCHK(hipEventRecord(gev.back().b, cs));
+    HIPCHK(hipEventSynchronize(gev.back().b));
     float d2h = 0.f;
-    HIPCHK(hipEventElapsedTime(&d2h, ev.a, ev.b));
-    sc->free_ev.push_back({ev.a, ev.b});
+    HIPCHK(hipEventElapsedTime(&d2h, gev.back().a, gev.back().b));   // last launch done -> last byte on the host
+    for (auto& e : gev) sc->free_ev.push_back({e.a, e.b});
     rt_tile_stats s;
     rc = collect_locked(sc, &s);
     if (rc) return rc;

@@ -135,12 +135,16 @@ class Scene:
                                                          C.c_void_p(stream) if stream else None),
                    "rt_scene_render_tile_device")
 
-    def render_tiles(self, reqs: Sequence[TileRequest], want_f32: bool = False):
-        """Batched: strips of one frame in ONE launch (rt_scene_render_tiles)."""
+    def render_tiles(self, reqs: Sequence[TileRequest], want_f32: bool = False, out=None):
+        """Batched: strips of one frame, host buffers out (rt_scene_render_tiles).  `out`: a list of uint8 arrays
+        from an earlier call to write into again (a caller that renders frame after frame keeps its pages warm)."""
         n = len(reqs)
         nb = self._lib.rt_tile_bytes(C.byref(reqs[0]))
         arr = (TileRequest * n)(*reqs)
-        outs = [np.empty(nb, np.uint8) for _ in range(n)]
+        if out is not None:
+            if len(out) != n or any(o.dtype != np.uint8 or o.size < nb or not o.flags.c_contiguous for o in out):
+                raise ValueError("out: need one contiguous uint8 array of at least rt_tile_bytes per request")
+        outs = out if out is not None else [np.empty(nb, np.uint8) for _ in range(n)]
         outf = [np.empty(nb, np.float32) for _ in range(n)] if want_f32 else None
         po = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
         pf = (C.c_void_p * n)(*[o.ctypes.data for o in outf]) if want_f32 else None
