@@ -513,6 +513,12 @@ __global__ __launch_bounds__(BLOCK, ISECT == 3 ? RT_MINWAVES_QTRAV : ISECT == 2 
                         if (need) retired = true;
                         break;
                     }
+#ifndef RT_TILES_TOP_DOWN
+                    // Tiles are handed out from the END of the batch backwards: strips are listed top to bottom and the
+                    // rows near the top of a frame are mostly sky (one segment per sample), so the launch ends on its
+                    // cheapest tiles and the tail in which waves run half empty is shorter.
+                    t = p.n_tiles - 1u - t;
+#endif
                     // decode the tile once, wave-uniformly: strip, tile origin, strip row offset and seed
                     const uint32_t st = t / p.tiles_per_strip;
                     const uint32_t rem = t - st * p.tiles_per_strip;
