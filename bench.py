@@ -42,6 +42,8 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "c5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the host-buffer (PCIe-inclusive) pass: profiling runs "
+                    "then see whole-frame launches only")
     ap.add_argument("--cpu-scale", type=int, default=1, help="CPU baseline renders the frame at 1/scale resolution")
     ap.add_argument("--flags", type=int, default=0, help="rt_tile_request.flags (1 = exact scan)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -181,7 +183,7 @@ def main():
     # (rt_scene_render_tiles: kernel launches + D2H copies into pageable host memory, the copies of all but
     # the last quarter of the strips overlapped with the last launch; d2h_ms = the exposed part), N = 1 only
     pcie = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_pcie:
         bufs, _, _ = scene.render_tiles(reqs)          # first pass touches the pages of the host buffers
         th0 = time.perf_counter()
         _, _, st_h = scene.render_tiles(reqs, out=bufs)
@@ -204,6 +206,13 @@ def main():
                 traffic = json.loads(tp.read_text()).get(args.workload, {}).get("bytes_per_launch")
             except Exception:
                 traffic = None
+        issue = None
+        ip = ROOT / "profiles" / "valu_issue.json"
+        if ip.exists():
+            try:
+                issue = json.loads(ip.read_text()).get(args.workload)
+            except Exception:
+                issue = None
         line = {
             "metric": "Mrays/sec @ 4K/8spp 1024-sphere" if args.workload == "c3" else f"Mrays/sec @ {args.workload}",
             "value": segs / elapsed / 1e6,
@@ -248,6 +257,9 @@ def main():
                         "ALGORITHMIC flops of the reference's linear closest-hit; the BVH-traversal engine reaches the "
                         "same bit-exact result with O(log N) tests per segment, so its frac is an algorithmic rate, "
                         "not an FMA issue rate (--flags 32 benches the linear engine: frac = issue-rate bound)",
+                # from the committed PMC pass of this workload (profiles/valu_issue.json), not measured live:
+                # share of the SIMDs' cycles in which a VALU instruction of this kernel holds the issue slot
+                "valu_issue": issue,
                 "hbm": {
                     "algorithmic_bytes_per_launch": hbm_bytes_per_launch,
                     "achieved_GBs": hbm_bytes_per_launch / avg_launch_s / 1e9,
