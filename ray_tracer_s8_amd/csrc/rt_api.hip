@@ -437,6 +437,7 @@ RT_API void rt_shutdown(void) {
 
 RT_API int rt_scene_create(int device, const rt_sphere* sp, uint32_t ns, const rt_triangle* tr, uint32_t nt,
                            rt_scene** out) {
+    const auto t_create0 = std::chrono::steady_clock::now();
     if (!out) return fail(RT_ERR_BAD_ARG, "out_scene is NULL");
     *out = nullptr;
     if ((ns && !sp) || (nt && !tr)) return fail(RT_ERR_BAD_ARG, "primitive pointer is NULL");
@@ -644,6 +645,10 @@ RT_API int rt_scene_create(int device, const rt_sphere* sp, uint32_t ns, const r
 #undef SC_CHK
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
+    if (getenv("RT_VERBOSE"))
+        fprintf(stderr, "[rt] scene: %u prims  bvh build %.2f ms (host)  uploads %.2f ms  total %.2f ms\n", np,
+                sc->bvh_build_ms, sc->h2d_ms,
+                std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_create0).count());
     *out = sc;
     return RT_OK;
 }

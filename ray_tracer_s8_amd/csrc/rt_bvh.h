@@ -17,7 +17,10 @@
 #pragma once
 #include <cmath>
 #include <cstdint>
+#include <algorithm>
+#include <atomic>
 #include <limits>
+#include <thread>
 #include <vector>
 
 namespace rtbvh {
@@ -103,29 +106,40 @@ inline FlatBVH build(const std::vector<Box>& prim) {
     FlatBVH out;
     out.leaf_of.assign(prim.size(), 0);
     if (prim.empty()) return out;                   // the reference recurses without bound here
+    // Work list of index RANGES over one array: a node's primitives are idx[begin, end), in the order the
+    // reference's recursion would hold them (children = the buckets' member lists concatenated in bucket order, each
+    // in its original relative order = a stable partition), so the halving fallback and the leaf order are the same.
     struct Item {
-        std::vector<uint32_t> idx;
+        uint32_t begin, end;
         uint32_t parent;
         Box as_seen_by_parent;
-        bool is_right = false;
-        uint32_t depth = 0;
+        bool is_right;
+        uint32_t depth;
+        uint32_t me;                 // node number
     };
-    std::vector<uint32_t> left_of, right_of, prim_of;   // per node (creation order)
-    std::vector<Item> stack;
-    {
-        Item root;
-        root.idx.resize(prim.size());
-        for (size_t i = 0; i < prim.size(); i++) root.idx[i] = (uint32_t)i;
-        root.parent = 0xffffffffu;
-        root.as_seen_by_parent = empty_box();
-        stack.push_back(std::move(root));
+    const uint32_t np = (uint32_t)prim.size();
+    std::vector<uint32_t> idx(np), tmp(np);
+    std::vector<uint8_t> bucket_of(np);
+    std::vector<float> cx(np), cy(np), cz(np);          // centroids once (aabb.rs:458-484)
+    for (uint32_t i = 0; i < np; i++) {
+        idx[i] = i;
+        float c[3];
+        center(prim[i], c);
+        cx[i] = c[0];
+        cy[i] = c[1];
+        cz[i] = c[2];
     }
-    out.nodes.reserve(prim.size() * 2);
+    const float* cen_of[3] = {cx.data(), cy.data(), cz.data()};
+    // Node numbers are the reference's creation order = depth first, left subtree first.  A subtree over m
+    // primitives has 2m - 1 nodes, so a node's number follows from its position (left child = me + 1, right child =
+    // me + 2 * m_left) and disjoint subtrees can be built by different threads into preallocated arrays.
+    const size_t n_nodes = 2 * (size_t)np - 1;
+    std::vector<uint32_t> left_of(n_nodes, 0xffffffffu), right_of(n_nodes, 0xffffffffu), prim_of(n_nodes, 0xffffffffu);
+    out.nodes.assign(n_nodes, FlatNode{{0, 0, 0}, 0, {0, 0, 0}, 0});
     const float EPS = 0.00001f;                     // bvh lib.rs:80
-    while (!stack.empty()) {
-        Item it = std::move(stack.back());
-        stack.pop_back();
-        const uint32_t me = (uint32_t)out.nodes.size();
+    // splits one node; returns false for a leaf, else fills L and R
+    auto split = [&](const Item& it, Item& L, Item& R) -> bool {
+        const uint32_t me = it.me;
         FlatNode fn;
         for (int i = 0; i < 3; i++) {
             fn.lo[i] = it.as_seen_by_parent.lo[i];
@@ -133,40 +147,39 @@ inline FlatBVH build(const std::vector<Box>& prim) {
         }
         fn.parent = it.parent;
         fn.pad = 0;
-        out.nodes.push_back(fn);
-        left_of.push_back(0xffffffffu);
-        right_of.push_back(0xffffffffu);
-        prim_of.push_back(0xffffffffu);
+        out.nodes[me] = fn;
         if (it.parent != 0xffffffffu) (it.is_right ? right_of : left_of)[it.parent] = me;
-        if (it.depth > out.depth) out.depth = it.depth;
-        if (it.idx.size() == 1) {                   // bvh_impl.rs:254-265
-            out.leaf_of[it.idx[0]] = me;
-            prim_of[me] = it.idx[0];
-            continue;
+        const uint32_t cnt_all = it.end - it.begin;
+        if (cnt_all == 1) {                         // bvh_impl.rs:254-265
+            out.leaf_of[idx[it.begin]] = me;
+            prim_of[me] = idx[it.begin];
+            return false;
         }
         // convex hull of the shapes and of their centroids (:247-251)
         Box all = empty_box(), cen = empty_box();
-        for (uint32_t s : it.idx) {
-            float c[3];
-            center(prim[s], c);
+        for (uint32_t k = it.begin; k < it.end; k++) {
+            const uint32_t s = idx[k];
             all = join(all, prim[s]);
-            for (int i = 0; i < 3; i++) {
-                cen.lo[i] = fminf(cen.lo[i], c[i]);
-                cen.hi[i] = fmaxf(cen.hi[i], c[i]);
-            }
+            cen.lo[0] = fminf(cen.lo[0], cx[s]);
+            cen.hi[0] = fmaxf(cen.hi[0], cx[s]);
+            cen.lo[1] = fminf(cen.lo[1], cy[s]);
+            cen.hi[1] = fmaxf(cen.hi[1], cy[s]);
+            cen.lo[2] = fminf(cen.lo[2], cz[s]);
+            cen.hi[2] = fmaxf(cen.hi[2], cz[s]);
         }
         const int ax = largest_axis(cen);
         const float extent = cen.hi[ax] - cen.lo[ax];
-        Item L, R;
-        L.parent = R.parent = me;
+        L = Item{0, 0, me, empty_box(), false, it.depth + 1, 0};
+        R = Item{0, 0, me, empty_box(), true, it.depth + 1, 0};
         auto halve = [&]() {                        // :277-291
-            const size_t h = it.idx.size() / 2;
-            L.idx.assign(it.idx.begin(), it.idx.begin() + h);
-            R.idx.assign(it.idx.begin() + h, it.idx.end());
+            const uint32_t h = cnt_all / 2;
+            L.begin = it.begin;
+            L.end = R.begin = it.begin + h;
+            R.end = it.end;
             L.as_seen_by_parent = empty_box();
-            for (uint32_t s : L.idx) L.as_seen_by_parent = join(L.as_seen_by_parent, prim[s]);
+            for (uint32_t k = L.begin; k < L.end; k++) L.as_seen_by_parent = join(L.as_seen_by_parent, prim[idx[k]]);
             R.as_seen_by_parent = empty_box();
-            for (uint32_t s : R.idx) R.as_seen_by_parent = join(R.as_seen_by_parent, prim[s]);
+            for (uint32_t k = R.begin; k < R.end; k++) R.as_seen_by_parent = join(R.as_seen_by_parent, prim[idx[k]]);
         };
         if (extent < EPS) {
             halve();
@@ -174,19 +187,18 @@ inline FlatBVH build(const std::vector<Box>& prim) {
             constexpr int NB = 6;
             size_t cnt[NB] = {0, 0, 0, 0, 0, 0};
             Box bb[NB];
-            std::vector<uint32_t> members[NB];
             for (int b = 0; b < NB; b++) bb[b] = empty_box();
-            for (uint32_t s : it.idx) {
-                float c[3];
-                center(prim[s], c);
-                const float rel = (c[ax] - cen.lo[ax]) / extent;
+            const float* ca = cen_of[ax];
+            for (uint32_t k = it.begin; k < it.end; k++) {
+                const uint32_t s = idx[k];
+                const float rel = (ca[s] - cen.lo[ax]) / extent;
                 const float fb = rel * ((float)NB - 0.01f);
                 size_t b = 0;                       // Rust `as usize`: truncate, saturate, NaN -> 0
                 if (fb == fb && fb > 0.0f) b = fb >= 1.8e19f ? (size_t)-1 : (size_t)fb;
                 if (b >= (size_t)NB) b = NB - 1;    // (the crate would index out of bounds)
                 cnt[b]++;
                 bb[b] = join(bb[b], prim[s]);
-                members[b].push_back(s);
+                bucket_of[k] = (uint8_t)b;
             }
             int best = 0;
             float best_cost = std::numeric_limits<float>::infinity();
@@ -210,17 +222,78 @@ inline FlatBVH build(const std::vector<Box>& prim) {
                     best_r = r;
                 }
             }
-            for (int b = 0; b <= best; b++) L.idx.insert(L.idx.end(), members[b].begin(), members[b].end());
-            for (int b = best + 1; b < NB; b++) R.idx.insert(R.idx.end(), members[b].begin(), members[b].end());
+            // stable counting sort of the range by bucket: the members of bucket 0, then 1, ... each in list order
+            uint32_t start[NB + 1];
+            start[0] = it.begin;
+            for (int b = 0; b < NB; b++) start[b + 1] = start[b] + (uint32_t)cnt[b];
+            uint32_t fill[NB];
+            for (int b = 0; b < NB; b++) fill[b] = start[b];
+            for (uint32_t k = it.begin; k < it.end; k++) tmp[fill[bucket_of[k]]++] = idx[k];
+            for (uint32_t k = it.begin; k < it.end; k++) idx[k] = tmp[k];
+            L.begin = it.begin;
+            L.end = R.begin = start[best + 1];
+            R.end = it.end;
             L.as_seen_by_parent = best_l;
             R.as_seen_by_parent = best_r;
-            if (L.idx.empty() || R.idx.empty()) halve();   // unreachable for finite centroids
+            if (L.begin == L.end || R.begin == R.end) halve();   // unreachable for finite centroids
         }
-        // left subtree is numbered first: push right, then left
-        R.is_right = true;
-        L.depth = R.depth = it.depth + 1;
-        stack.push_back(std::move(R));
-        stack.push_back(std::move(L));
+        L.me = me + 1;
+        R.me = me + 2 * (L.end - L.begin);
+        return true;
+    };
+    // whole subtree below one item, depth first; returns the deepest level reached
+    auto subtree = [&](const Item& top) -> uint32_t {
+        uint32_t deepest = top.depth;
+        std::vector<Item> stack{top};
+        while (!stack.empty()) {
+            const Item it = stack.back();
+            stack.pop_back();
+            if (it.depth > deepest) deepest = it.depth;
+            Item L, R;
+            if (split(it, L, R)) {
+                stack.push_back(R);
+                stack.push_back(L);
+            }
+        }
+        return deepest;
+    };
+    const Item root{0u, np, 0xffffffffu, empty_box(), false, 0u, 0u};
+    unsigned hw = std::thread::hardware_concurrency();
+    const unsigned n_thr = np < 16384 ? 1u : std::min(8u, hw ? hw : 1u);
+    if (n_thr <= 1) {
+        out.depth = subtree(root);
+    } else {
+        // the top of the tree on this thread until there are enough subtrees to share out, then one worker per chunk
+        std::vector<Item> open{root}, work;
+        while (!open.empty() && open.size() + work.size() < 8 * n_thr) {
+            size_t big = 0;                          // split the largest open item next
+            for (size_t i = 1; i < open.size(); i++)
+                if (open[i].end - open[i].begin > open[big].end - open[big].begin) big = i;
+            const Item it = open[big];
+            open.erase(open.begin() + (long)big);
+            if (it.depth > out.depth) out.depth = it.depth;
+            if (it.end - it.begin < 1024) {
+                work.push_back(it);
+                continue;
+            }
+            Item L, R;
+            if (split(it, L, R)) {
+                open.push_back(L);
+                open.push_back(R);
+            }
+        }
+        work.insert(work.end(), open.begin(), open.end());
+        std::sort(work.begin(), work.end(), [](const Item& a, const Item& b) { return a.end - a.begin > b.end - b.begin; });
+        std::atomic<size_t> next{0};
+        std::vector<uint32_t> deepest(n_thr, 0);
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < n_thr; t++)
+            pool.emplace_back([&, t] {
+                for (size_t i = next.fetch_add(1); i < work.size(); i = next.fetch_add(1))
+                    deepest[t] = std::max(deepest[t], subtree(work[i]));
+            });
+        for (std::thread& th : pool) th.join();
+        for (uint32_t dpt : deepest) out.depth = std::max(out.depth, dpt);
     }
     // traversal form: internal nodes only, numbered in creation order
     std::vector<uint32_t> trav_id(out.nodes.size(), 0xffffffffu);

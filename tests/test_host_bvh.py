@@ -18,7 +18,7 @@ def host():
     OUT.parent.mkdir(exist_ok=True)
     hdr = ROOT / "ray_tracer_s8_amd" / "csrc" / "rt_bvh.h"
     if not OUT.exists() or OUT.stat().st_mtime < max(SRC.stat().st_mtime, hdr.stat().st_mtime):
-        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", f"-I{hdr.parent}", "-o", str(OUT),
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-ffp-contract=off", f"-I{hdr.parent}", "-o", str(OUT),
                         str(SRC)], check=True)
     return C.CDLL(str(OUT))
 

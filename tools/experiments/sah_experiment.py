@@ -6,7 +6,7 @@ ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT))
 from ray_tracer_s8_amd import scenes
 so = Path("/tmp/libsah_exp.so")
-subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", f"-I{ROOT / 'ray_tracer_s8_amd' / 'csrc'}", "-o", str(so),
+subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", f"-I{ROOT / 'ray_tracer_s8_amd' / 'csrc'}", "-o", str(so),
                 str(Path(__file__).with_suffix(".cpp"))], check=True)
 lib = C.CDLL(str(so))
 for name in ("c3", "c5"):
