@@ -19,11 +19,14 @@ LIB_PATH = LIB_DIR / "librt_s8.so"
 # -ffp-contract=off: the kernel must perform the reference's IEEE binary32 operations one
 # by one (Rust never contracts a*b+c); FMA appears only where written as __builtin_fmaf.
 # Correctly rounded f32 sqrt/div is hipcc's default (-fhip-fp32-correctly-rounded-divide-sqrt).
+# -fno-unroll-loops: only the loops marked `#pragma unroll` are unrolled; the heuristic unrolling of the divergent
+# loops (samplers, root tests, path product) cost c3 3 % (tools/variants_all.sh).
 HIPCC_FLAGS = [
     "--offload-arch=gfx950",
     "-O3",
     "-std=c++17",
     "-ffp-contract=off",
+    "-fno-unroll-loops",
     "-fPIC",
     "-shared",
     "-fvisibility=hidden",
