@@ -262,10 +262,7 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     const bool qnodes = traverse && sc->quant_ok && !(rq->flags & RT_FLAG_EXACT_NODES) &&
                         ((rq->flags & RT_FLAG_QUANT_NODES) ||
                          (n_prims >= RT_QNODES_MIN_PRIMS && sc->leaf_density < RT_QNODES_MAX_DENSITY));
-    void (*kern)(rtk::KParams) =
-        traverse ? (qnodes ? rtk::rt_tile_kernel<3, false> : rtk::rt_tile_kernel<2, false>)
-                 : streamed ? (expanded ? rtk::rt_tile_kernel<1, true> : rtk::rt_tile_kernel<1, false>)
-                            : (expanded ? rtk::rt_tile_kernel<0, true> : rtk::rt_tile_kernel<0, false>);
+    const rtk::KernelFn kern = traverse ? rtk::kernel_traverse(qnodes) : rtk::kernel_linear(streamed, expanded);
     HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, rtk::BLOCK, lds));
     if (per_cu < 1) per_cu = 1;
     static const bool verbose = getenv("RT_VERBOSE") != nullptr;
@@ -403,18 +400,13 @@ static int ensure_ctx(DeviceCtx* c) {
     if (c->stream) return RT_OK;
     HIPCHK(hipSetDevice(c->dev));
     HIPCHK(hipDeviceGetAttribute(&c->n_cu, hipDeviceAttributeMultiprocessorCount, c->dev));
-    HIPCHK(hipFuncSetAttribute((const void*)rtk::rt_tile_kernel<0, false>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
-    HIPCHK(hipFuncSetAttribute((const void*)rtk::rt_tile_kernel<0, true>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
-    HIPCHK(hipFuncSetAttribute((const void*)rtk::rt_tile_kernel<1, false>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
-    HIPCHK(hipFuncSetAttribute((const void*)rtk::rt_tile_kernel<1, true>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
-    HIPCHK(hipFuncSetAttribute((const void*)rtk::rt_tile_kernel<2, false>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
-    HIPCHK(hipFuncSetAttribute((const void*)rtk::rt_tile_kernel<3, false>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
+    for (int streamed = 0; streamed < 2; streamed++)
+        for (int expanded = 0; expanded < 2; expanded++)
+            HIPCHK(hipFuncSetAttribute((const void*)rtk::kernel_linear(streamed != 0, expanded != 0),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
+    for (int quantised = 0; quantised < 2; quantised++)
+        HIPCHK(hipFuncSetAttribute((const void*)rtk::kernel_traverse(quantised != 0),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
     hipStream_t st = nullptr, cs = nullptr;
     HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));

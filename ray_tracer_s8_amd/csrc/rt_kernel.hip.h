@@ -1047,4 +1047,9 @@ __global__ __launch_bounds__(BLOCK, ISECT == 3 ? RT_MINWAVES_QTRAV : ISECT == 2 
     }
 }
 
+// The kernels are instantiated in rt_kernels_lin.hip / rt_kernels_trav.hip; the host side (rt_api.hip) gets them here.
+using KernelFn = void (*)(const KParams);
+KernelFn kernel_linear(bool streamed, bool expanded);
+KernelFn kernel_traverse(bool quantised);
+
 }  // namespace rtk
