@@ -55,6 +55,9 @@ constexpr int TRAV_STACK = 64;   // traversal stack entries per lane (host falls
 #ifndef RT_STEPS_PER_CHECK
 #define RT_STEPS_PER_CHECK 8
 #endif
+#ifndef RT_STEPS_PER_CHECK_Q    // quantised-node kernel (large scenes, long walks): c5 +1 % over 8
+#define RT_STEPS_PER_CHECK_Q 16
+#endif
 #ifndef RT_REFILL_EIGHTHS
 #define RT_REFILL_EIGHTHS 3
 #endif
@@ -692,7 +695,7 @@ __global__ __launch_bounds__(BLOCK, ISECT == 3 ? RT_MINWAVES_QTRAV : ISECT == 2 
 #else
 #pragma unroll
 #endif
-                for (int rep = 0; rep < RT_STEPS_PER_CHECK; rep++)
+                for (int rep = 0; rep < (QNODES ? RT_STEPS_PER_CHECK_Q : RT_STEPS_PER_CHECK); rep++)
                 if (in_trav) {
                     WCOUNT(5);
                     LCOUNT(5);
