@@ -428,6 +428,13 @@ __device__ __forceinline__ uint8_t f32_as_u8(float v) {
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 
+// Element `i` of a device array reached through a 32-bit byte offset from its (wave-uniform) base pointer: one shift /
+// multiply and the scalar-base addressing mode instead of 64-bit address arithmetic per lane.  Arrays stay < 4 GiB.
+template <class T>
+__device__ __forceinline__ const T& at32(const T* __restrict__ base, uint32_t i) {
+    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + i * (uint32_t)sizeof(T));
+}
+
 // ------------------------------------------------------------------ the kernel
 // ISECT selects the closest-hit engine: 0 = linear scan, scene resident in LDS; 1 = linear scan, scene streamed
 // through LDS in chunks; 2 = per-lane traversal of the reference BVH (exact 64-byte nodes); 3 = the same walk over
@@ -657,12 +664,12 @@ __global__ __launch_bounds__(BLOCK, ISECT == 3 ? RT_MINWAVES_QTRAV : ISECT == 2 
                     // lazily: only to a hit that would replace the running closest one.  (A lane without a finite
                     // inverse direction walked the exact nodes: nothing to validate.)
                     if (prim < p.n_sph) {
-                        const float4 g = p.geom[prim];
+                        const float4 g = at32(p.geom, prim);
                         if (exact_sphere(o, td, mk(g.x, g.y, g.z), g.w, p.t_min, p.t_max, t)) {
                             if (QNODES)
                                 consider_if(h, (int)prim, o, d, t, [&]() {
                                     if (!qfin || (p.n_sph + p.n_tri) == 1) return true;
-                                    const float4 s = p.geom_r[prim];
+                                    const float4 s = at32(p.geom_r, prim);
                                     return intersects_aabb_finite(o, aux, make_float4(s.x - s.w, s.y - s.w, s.z - s.w, 0.f),
                                                                   make_float4(s.x + s.w, s.y + s.w, s.z + s.w, 0.f));
                                 });
@@ -717,7 +724,9 @@ __global__ __launch_bounds__(BLOCK, ISECT == 3 ? RT_MINWAVES_QTRAV : ISECT == 2 
                         bool hl, hr;
                         uint32_t cl, cr;
                         if (QNODES) {
-                            uint4 qa = p.travq[2 * (size_t)t_ref], qb = p.travq[2 * (size_t)t_ref + 1];
+                            // (32-bit byte offset from the uniform base: one shift and the scalar-base addressing mode)
+                            const uint4* __restrict__ nq = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.travq) + (t_ref << 5));
+                            uint4 qa = nq[0], qb = nq[1];
                             asm volatile("" : "+v"(qb.x), "+v"(qb.y), "+v"(qb.z), "+v"(qb.w));   // keep the two 16-byte loads whole
                             cl = qb.z;
                             cr = qb.w;
@@ -746,12 +755,12 @@ __global__ __launch_bounds__(BLOCK, ISECT == 3 ? RT_MINWAVES_QTRAV : ISECT == 2 
                             } else {
                                 // +-0 direction component (inverse = +-inf): the monotonicity argument does not hold, so
                                 // this lane walks the exact nodes with the crate's literal test; its leaves need no validation
-                                const float4* __restrict__ nd = p.trav + 4 * (size_t)t_ref;
+                                const float4* __restrict__ nd = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.trav) + (t_ref << 6));
                                 hl = intersects_aabb(o, aux, nd[0], nd[1]);
                                 hr = intersects_aabb(o, aux, nd[2], nd[3]);
                             }
                         } else {
-                            const float4* __restrict__ nd = p.trav + 4 * (size_t)t_ref;
+                            const float4* __restrict__ nd = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.trav) + (t_ref << 6));
                             const float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
                             if (aux.finite) {                    // (RT_FLAG_FULL_CHAIN also forces the crate's literal form)
                                 hl = intersects_aabb_finite(o, aux, n0, n1);
@@ -943,8 +952,8 @@ __global__ __launch_bounds__(BLOCK, ISECT == 3 ? RT_MINWAVES_QTRAV : ISECT == 2 
             if (h.idx >= 0) {
                 WCOUNT(8);
                 LCOUNT(8);
-                const float em = p.emis[h.idx];
-                const float4 m = p.mat[h.idx];
+                const float em = at32(p.emis, (uint32_t)h.idx);
+                const float4 m = at32(p.mat, (uint32_t)h.idx);
                 if (em > 0.0f) {                              // main.rs:116-117
                     term_r = m.x * em;
                     term_g = m.y * em;
@@ -953,7 +962,7 @@ __global__ __launch_bounds__(BLOCK, ISECT == 3 ? RT_MINWAVES_QTRAV : ISECT == 2 
                 } else {
                     V3 n;
                     if ((uint32_t)h.idx < p.n_sph) {
-                        float4 g = p.geom[h.idx];
+                        float4 g = at32(p.geom, (uint32_t)h.idx);
                         n = normalize_or_zero(h.p - mk(g.x, g.y, g.z));             // sphere.rs:49-51
                     } else {
                         const float* tv = p.tri + 9 * (size_t)(h.idx - p.n_sph);
@@ -1008,7 +1017,7 @@ __global__ __launch_bounds__(BLOCK, ISECT == 3 ? RT_MINWAVES_QTRAV : ISECT == 2 
                     LCOUNT(11);
                     uint32_t idx = p.path32 ? reinterpret_cast<uint32_t*>(lpath)[i * BLOCK + tid]
                                             : (uint32_t) reinterpret_cast<uint16_t*>(lpath)[i * BLOCK + tid];
-                    float4 m = p.mat[idx];
+                    float4 m = at32(p.mat, (uint32_t)idx);
                     term_r = m.x * term_r;
                     term_g = m.y * term_g;
                     term_b = m.z * term_b;
