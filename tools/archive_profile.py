@@ -38,8 +38,10 @@ if valu and busy:
     di[workload] = {"valu_insts_per_launch": insts, "kernel_cycles": cycles, "simds": 1024,
                     "issue_frac": valu * 4.0 / (1024.0 * cycles),
                     "active_lanes_per_valu_inst": (thr / insts) if thr and insts else None,
-                    "note": "SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x SQ_BUSY_CYCLES / 32 SEs); a wave64 VALU "
-                            "instruction holds its SIMD's issue slot for 4 cycles", "round": rnd}
+                    "note": "SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x SQ_BUSY_CYCLES / 32 SEs): every VALU instruction "
+                            "counted as one 4-cycle quad.  An UPPER bound on pipe occupancy: plain FP32 VOP2 ops retire in "
+                            "about 2.3 cycles on this chip (tools/ubench), and a build with 5 % fewer VALU instructions was "
+                            "not faster (DESIGN.md 4.7)", "round": rnd}
     json.dump(di, open(pi, "w"), indent=1)
     print(json.dumps(di, indent=1))
 print(open(f"profiles/{rnd}_{workload}_kernel_stats.csv").read())
