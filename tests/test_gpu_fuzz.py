@@ -73,3 +73,52 @@ def test_fuzz_case(ndev, oracle, i):
     assert np.array_equal(rgb, ref), f"case {i}: {int((rgb != ref).sum())} bytes differ (flags {flags})"
     assert np.array_equal(f32.view(np.uint32), ref_f.view(np.uint32)), f"case {i}"
     assert st.ray_segments == info["ray_segments"], f"case {i}"
+
+
+def _big_case(i):
+    """Large scenes for the traversal engines: thousands of spheres in different distributions (uniform fields, tight
+    clusters, sheets, radius ratios up to 1:2000 with a ground sphere), medium frames."""
+    g = np.random.default_rng(5000 + i)
+    n = int(g.choice([3000, 6000, 12000, 30000]))
+    kind = i % 4
+    sph = np.zeros(n, _abi.SPHERE_DTYPE)
+    if kind == 0:                                   # uniform field
+        c = g.uniform([-40, -1, -90], [40, 15, -3], (n, 3))
+        r = g.uniform(0.1, 0.5, n)
+    elif kind == 1:                                 # tight clusters
+        k = g.uniform([-30, 0, -70], [30, 10, -5], (24, 3))
+        c = k[g.integers(0, 24, n)] + g.normal(0, 0.8, (n, 3))
+        r = g.uniform(0.02, 0.15, n)
+    elif kind == 2:                                 # a thin sheet (small extent along y)
+        c = g.uniform([-25, 1.0, -60], [25, 1.05, -4], (n, 3))
+        r = g.uniform(0.05, 0.2, n)
+    else:                                           # dense overlap (leaf density >> 2): exact-node kernel by the heuristic
+        c = g.uniform([-6, -1, -20], [6, 5, -4], (n, 3))
+        r = g.uniform(0.2, 0.6, n)
+    sph["cx"], sph["cy"], sph["cz"], sph["radius"] = c[:, 0], c[:, 1], c[:, 2], r
+    sph["cx"][0], sph["cy"][0], sph["cz"][0], sph["radius"][0] = 0.0, -1001.0, -20.0, 1000.0   # ground
+    for ch in ("albedo_r", "albedo_g", "albedo_b"):
+        sph[ch] = g.uniform(0.1, 0.95, n)
+    sph["roughness"] = g.choice([0.0, 0.0, 0.4, 1.0], n)
+    sph["emission"] = np.where(g.uniform(size=n) < 0.03, g.uniform(2, 6, n), 0.0)
+    rq = _abi.default_request(width=int(g.choice([160, 256])), height=int(g.choice([90, 144])), divisions=1, spp=2,
+                              max_bounces=int(g.choice([4, 8])), seed=int(g.integers(0, 2**63)))
+    flags = [0, _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_QUANT_NODES, _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_EXACT_NODES][i % 3]
+    return sph, rq, flags
+
+
+N_BIG = int(os.environ.get("RT_FUZZ_BIG", "6"))           # RT_FUZZ_BIG=60 for a long soak
+
+
+@pytest.mark.parametrize("i", range(N_BIG))
+def test_fuzz_big_scene(ndev, oracle, i):
+    sph, rq, flags = _big_case(i)
+    ref, ref_f, info = oracle.render(rq, sph, backend=1, want_f32=True)
+    r = rq.copy()
+    r.flags = flags
+    with rt.Scene(0, rt.World(sph)) as sc:
+        rgb, f32, st = sc.render_tile(r, want_f32=True)
+    assert st.engine in (2, 3)
+    assert np.array_equal(rgb, ref), f"big case {i}: {int((rgb != ref).sum())} bytes differ (flags {flags}, engine {st.engine})"
+    assert np.array_equal(f32.view(np.uint32), ref_f.view(np.uint32)), f"big case {i}"
+    assert st.ray_segments == info["ray_segments"], f"big case {i}"
