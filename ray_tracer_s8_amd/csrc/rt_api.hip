@@ -57,7 +57,7 @@ constexpr uint32_t STREAM_CHUNK = 2048;         // chunk size when streaming thr
 constexpr uint32_t TRAVERSE_MIN_TRIS = 64;      // ... or above this many triangles
 constexpr uint32_t RT_QNODES_MIN_PRIMS = 4096;   // from here up, and below this leaf density, the traversal walks the
 constexpr float RT_QNODES_MAX_DENSITY = 2.0f;    // 32-byte quantised nodes (measured, tools/crossover_q.py)
-constexpr uint32_t TRAVERSE_MIN_PRIMS = 512;    // above this many primitives the BVH-traversal engine is the default (measured crossover, tools/crossover.py)
+constexpr uint32_t TRAVERSE_MIN_PRIMS = 384;    // above this many primitives the BVH-traversal engine is the default (measured crossover, tools/crossover.py: 0.92 at 256, 1.11 at 512)
 
 }  // namespace
 
