@@ -186,13 +186,19 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     // (the linear engines test every triangle's box per segment: meshes switch to the tree much earlier)
     const bool traverse = trav_ok && ((rq->flags & RT_FLAG_BVH_TRAVERSE) || n_prims > TRAVERSE_MIN_PRIMS ||
                                       sc->n_tri > TRAVERSE_MIN_TRIS);
+    // node format: the halved gather footprint pays once the 64-byte node array is far larger than the per-CU
+    // caches and the rays reach few leaves (c5: +24 %); small or dense scenes are bound by the leaf tests, where
+    // the exact-node kernel's 5 waves/SIMD win (c3: +3 %, dense fields: +10 %).  tools/crossover_q.py, DESIGN.md 4.7
+    const bool qnodes = traverse && sc->quant_ok && !(rq->flags & RT_FLAG_EXACT_NODES) &&
+                        ((rq->flags & RT_FLAG_QUANT_NODES) ||
+                         (n_prims >= RT_QNODES_MIN_PRIMS && sc->leaf_density < RT_QNODES_MAX_DENSITY));
     const bool streamed = !traverse && sc->n_sph_pad > RESIDENT_MAX;
     p.chunk = traverse ? 0 : (streamed ? STREAM_CHUNK : sc->n_sph_pad);
     p.n_chunks = p.chunk ? (sc->n_sph_pad + p.chunk - 1) / p.chunk : 0;
     p.path32 = (sc->n_sph + sc->n_tri) > 65536u ? 1u : 0u;
     size_t geom_bytes = traverse ? 0 : (size_t)(p.chunk ? p.chunk : 1) * sizeof(float4);
     p.lds_cand_off = (uint32_t)geom_bytes;
-    size_t cand_bytes = traverse ? (size_t)rtk::MAXL * rtk::BLOCK * sizeof(uint32_t)
+    size_t cand_bytes = traverse ? (size_t)(qnodes ? rtk::MAXL : rtk::MAXL_EXACT) * rtk::BLOCK * sizeof(uint32_t)
                                  : (size_t)rtk::MAXC * rtk::BLOCK * sizeof(uint16_t);
     p.lds_path_off = (uint32_t)(geom_bytes + cand_bytes);
     size_t path_bytes = (size_t)p.depth * rtk::BLOCK * (p.path32 ? 4 : 2);
@@ -256,12 +262,6 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
 
     // persistent grid: as many workgroups as the chip holds at this LDS/VGPR budget
     int per_cu = 0;
-    // node format: the halved gather footprint pays once the 64-byte node array is far larger than the per-CU
-    // caches and the rays reach few leaves (c5: +24 %); small or dense scenes are bound by the leaf tests, where
-    // the exact-node kernel's 5 waves/SIMD win (c3: +3 %, dense fields: +10 %).  tools/crossover_q.py, DESIGN.md 4.7
-    const bool qnodes = traverse && sc->quant_ok && !(rq->flags & RT_FLAG_EXACT_NODES) &&
-                        ((rq->flags & RT_FLAG_QUANT_NODES) ||
-                         (n_prims >= RT_QNODES_MIN_PRIMS && sc->leaf_density < RT_QNODES_MAX_DENSITY));
     const rtk::KernelFn kern = traverse ? rtk::kernel_traverse(qnodes) : rtk::kernel_linear(streamed, expanded);
     HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, rtk::BLOCK, lds));
     if (per_cu < 1) per_cu = 1;

@@ -27,6 +27,7 @@
 //   * one launch serves a batch of strips (same frame, any division_no / seed).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 namespace rtk {
@@ -39,7 +40,7 @@ constexpr int BLOCK = 256;       // 4 waves
 #define RT_MINWAVES 4
 #endif
 #ifndef RT_MINWAVES_TRAV
-#define RT_MINWAVES_TRAV 5
+#define RT_MINWAVES_TRAV 6       // exact-node kernel: 80 VGPRs, 2 spill slots outside the loops; c3 +1 %, c4 +2 % over 5
 #endif
 #ifndef RT_MINWAVES_QTRAV       // quantised-node traversal: 114 VGPRs; 5 waves/SIMD spills 41 of them (slower)
 #define RT_MINWAVES_QTRAV 4
@@ -52,6 +53,9 @@ constexpr int TRAV_STACK = 64;   // traversal stack entries per lane (host falls
 #ifndef RT_MAXL
 #define RT_MAXL 8
 #endif
+#ifndef RT_MAXL_EXACT           // exact-node kernel: 7 KiB of leaf lists lets six of its workgroups share a CU's LDS
+#define RT_MAXL_EXACT 7
+#endif
 #ifndef RT_STEPS_PER_CHECK
 #define RT_STEPS_PER_CHECK 8
 #endif
@@ -62,6 +66,7 @@ constexpr int TRAV_STACK = 64;   // traversal stack entries per lane (host falls
 #define RT_REFILL_EIGHTHS 3
 #endif
 constexpr int MAXL = RT_MAXL;    // leaf-candidate slots per lane in traversal mode (flushed when full)
+constexpr int MAXL_EXACT = RT_MAXL_EXACT;
 constexpr uint32_t LEAF_BIT = 0x80000000u;
 
 struct StripDesc {
@@ -445,6 +450,7 @@ __global__ __launch_bounds__(BLOCK, ISECT == 3 ? RT_MINWAVES_QTRAV : ISECT == 2 
     constexpr bool STREAMED = (ISECT == 1);
     constexpr bool TRAVERSE = (ISECT >= 2);
     constexpr bool QNODES = (ISECT == 3);            // traversal over 32-byte conservatively quantised nodes
+    constexpr uint32_t ML = (ISECT == 2) ? (uint32_t)MAXL_EXACT : (uint32_t)MAXL;   // leaf-list slots per lane
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     float4* lgeom = reinterpret_cast<float4*>(lds_raw);          // pair layout, see KParams::geom_pk / geom_px
     const float* lgeomf = reinterpret_cast<const float*>(lds_raw);
@@ -489,7 +495,9 @@ __global__ __launch_bounds__(BLOCK, ISECT == 3 ? RT_MINWAVES_QTRAV : ISECT == 2 
     bool bounce = false;         // need_ray kind: false = camera ray of a new sample, true = scattered ray
     V3 bn = mk(0, 0, 0);         // bounce: surface normal at the hit
     float brough = 0.f;          // bounce: roughness of the hit material
-    unsigned long long n_seg = 0, n_cand = 0, n_fall = 0;
+    // per-lane statistics.  Traversal kernels (register-bound): 32-bit, drained into the 64-bit totals before they can wrap
+    using Cnt = typename std::conditional<(ISECT >= 2), uint32_t, unsigned long long>::type;
+    Cnt n_seg = 0, n_cand = 0, n_fall = 0;
     // ---- closest-hit query state.  The linear engines finish a query inside one loop iteration; the traversal
     // engine keeps it across iterations (in_trav) so that lanes whose traversal ended can be refilled while
     // stragglers keep walking.
@@ -498,7 +506,7 @@ __global__ __launch_bounds__(BLOCK, ISECT == 3 ? RT_MINWAVES_QTRAV : ISECT == 2 
     h.dist = 0.f;
     h.p = mk(0, 0, 0);
     RayAux aux = ray_aux(mk(1.f, 1.f, 1.f), false);
-    V3 td = mk(0, 0, 0);
+    V3 td = mk(0, 0, 0);                     // linear engines: 2 * d of the current segment
     bool in_trav = false;
     uint32_t t_ref = 0, t_sp = 0, t_cnt = 0;
     V3 ig = mk(0, 0, 0), cq = mk(0, 0, 0);   // QNODES: the ray in grid units, t(q) = q * ig + cq
@@ -506,8 +514,18 @@ __global__ __launch_bounds__(BLOCK, ISECT == 3 ? RT_MINWAVES_QTRAV : ISECT == 2 
     uint32_t* lc32 = reinterpret_cast<uint32_t*>(lds_raw + p.lds_cand_off);     // TRAVERSE: leaf candidates (u32)
     uint32_t* lstack = reinterpret_cast<uint32_t*>(lds_raw + p.lds_stack_off);   // TRAVERSE: per-lane stack
 
+    auto drain_counters = [&]() {
+        const unsigned long long ws = wave_sum(n_seg), wc = wave_sum(n_cand), wf = wave_sum(n_fall);
+        if (lane == (int)__builtin_ctzll(__ballot(true))) {
+            atomicAdd(&p.counters[0], ws);
+            atomicAdd(&p.counters[1], wc);
+            atomicAdd(&p.counters[2], wf);
+        }
+        n_seg = n_cand = n_fall = 0;
+    };
     for (;;) {
         WCOUNT(0);
+        if (TRAVERSE && __ballot(((n_seg | n_cand | n_fall) & 0x80000000u) != 0)) drain_counters();
         // ================= pixel acquisition: lanes pull pixels of the wave's current tile
         {
             bool need = !have_pixel && !retired;
@@ -626,7 +644,7 @@ __global__ __launch_bounds__(BLOCK, ISECT == 3 ? RT_MINWAVES_QTRAV : ISECT == 2 
         if (active && !in_trav) {                            // a new closest-hit query starts
             h.idx = -1;
             aux = ray_aux(d, (p.flags & 8u) != 0);
-            td = 2.0f * d;                                   // (2f32 * ray.direction), sphere.rs:44
+            if (!TRAVERSE) td = 2.0f * d;                    // (2f32 * ray.direction), sphere.rs:44
             n_seg++;
             if (QNODES) {
                 // the ray in grid units: t(q) = q * ig + cq with ig = step * inv, cq = -((o - base) / step) * ig
@@ -665,7 +683,7 @@ __global__ __launch_bounds__(BLOCK, ISECT == 3 ? RT_MINWAVES_QTRAV : ISECT == 2 
                     // inverse direction walked the exact nodes: nothing to validate.)
                     if (prim < p.n_sph) {
                         const float4 g = at32(p.geom, prim);
-                        if (exact_sphere(o, td, mk(g.x, g.y, g.z), g.w, p.t_min, p.t_max, t)) {
+                        if (exact_sphere(o, 2.0f * d, mk(g.x, g.y, g.z), g.w, p.t_min, p.t_max, t)) {   // (2f32 * ray.direction), sphere.rs:44
                             if (QNODES)
                                 consider_if(h, (int)prim, o, d, t, [&]() {
                                     if (!qfin || (p.n_sph + p.n_tri) == 1) return true;
@@ -695,7 +713,7 @@ __global__ __launch_bounds__(BLOCK, ISECT == 3 ? RT_MINWAVES_QTRAV : ISECT == 2 
 #ifndef RT_FLUSH_INLINE
                 // a lane whose leaf list is full waits at its leaf until this point (keeps the root tests out of the
                 // unrolled step code: one copy instead of RT_STEPS_PER_CHECK; c3 +1 %, 45 % less code)
-                if (in_trav && t_cnt == (uint32_t)MAXL) flush();
+                if (in_trav && t_cnt == ML) flush();
 #endif
 #ifdef RT_ROLL_STEPS
 #pragma clang loop unroll(disable)
@@ -708,9 +726,9 @@ __global__ __launch_bounds__(BLOCK, ISECT == 3 ? RT_MINWAVES_QTRAV : ISECT == 2 
                     LCOUNT(5);
                     if (t_ref & LEAF_BIT) {
 #ifdef RT_FLUSH_INLINE
-                        if (t_cnt == (uint32_t)MAXL) flush();
+                        if (t_cnt == ML) flush();
 #else
-                        if (t_cnt == (uint32_t)MAXL) continue;
+                        if (t_cnt == ML) continue;
 #endif
                         lc32[t_cnt * BLOCK + tid] = t_ref & ~LEAF_BIT;
                         t_cnt++;
@@ -1051,12 +1069,7 @@ __global__ __launch_bounds__(BLOCK, ISECT == 3 ? RT_MINWAVES_QTRAV : ISECT == 2 
         }
     }
 
-    unsigned long long ws = wave_sum(n_seg), wc = wave_sum(n_cand), wf = wave_sum(n_fall);
-    if (lane == 0) {
-        atomicAdd(&p.counters[0], ws);
-        atomicAdd(&p.counters[1], wc);
-        atomicAdd(&p.counters[2], wf);
-    }
+    drain_counters();
 }
 
 // The kernels are instantiated in rt_kernels_lin.hip / rt_kernels_trav.hip; the host side (rt_api.hip) gets them here.
