@@ -488,3 +488,20 @@ def test_quantised_walk_fallback_lanes(ndev, oracle, flags):
     rq2 = _abi.default_request(width=65, height=65, divisions=1, spp=4, max_bounces=6, seed=9)
     rq2.aperture = 0.0
     _compare(oracle, rq2, np.concatenate([row, sph]), flags=flags)
+
+
+@pytest.mark.parametrize("flags", [0, _abi.RT_FLAG_EXACT_NODES, _abi.RT_FLAG_LINEAR_SCAN])
+def test_more_than_65536_primitives(ndev, oracle, flags):
+    """Primitive indices beyond 16 bits: the path stack switches to 32-bit entries (KParams::path32), leaf references and
+    candidate lists carry 17+ bits; spheres and a few triangles (indices >= n_spheres) in one scene."""
+    sph = scenes.rand65536(n=70000)
+    g = np.random.default_rng(11)
+    tri = np.zeros(40, _abi.TRIANGLE_DTYPE)
+    for t in range(40):
+        c = np.array([g.uniform(-20, 20), g.uniform(0, 8), g.uniform(-40, -6)])
+        tri["a"][t], tri["b"][t], tri["c"][t] = c, c + g.uniform(-2, 2, 3), c + g.uniform(-2, 2, 3)
+        tri["albedo_r"][t], tri["albedo_g"][t], tri["albedo_b"][t] = g.uniform(0.2, 0.9, 3)
+        tri["roughness"][t] = g.choice([0.0, 1.0])
+    rq = _abi.default_request(width=96, height=54, divisions=1, spp=2, max_bounces=6, seed=77)
+    st = _compare(oracle, rq, sph, tri, flags=flags)
+    assert st.engine == {0: 3, _abi.RT_FLAG_EXACT_NODES: 2, _abi.RT_FLAG_LINEAR_SCAN: 1}[flags]
