@@ -101,9 +101,10 @@ class ControllerService:
             self._jobs[job_id] = {"meta": meta, "result": []}
         infos = [RenderInfo(world, meta, k, self.settings) for k in range(self.divisions)]
         if self.slave_urls is not None:
+            world_text = wire.world_to_json_text(world)                # the same world goes out with every strip
             for k, info in enumerate(infos):                            # one POST per division (main.rs:47-75)
                 url = self.slave_urls[k % len(self.slave_urls)]
-                req = urllib.request.Request(url, data=wire.encode_render_info(info).encode(),
+                req = urllib.request.Request(url, data=wire.encode_render_info(info, world_text).encode(),
                                              headers={"Content-Type": "application/json"}, method="POST")
                 with urllib.request.urlopen(req, timeout=60) as r:
                     log.info("Response from slave: %s", r.read().decode(errors="replace"))

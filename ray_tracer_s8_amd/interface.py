@@ -10,6 +10,7 @@ replaces dispatch + assembly (controller main.rs:47-75, 109-119) with GPUs as th
 from __future__ import annotations
 
 import ctypes as C
+import hashlib
 import uuid
 from dataclasses import dataclass, field
 from typing import Optional, Sequence
@@ -181,8 +182,12 @@ class Slave:
         self._scene_key = None
 
     def render(self, info: RenderInfo) -> ImageSlice:
-        key = (id(info.world.spheres), id(info.world.triangles))
-        if self._scene is None or self._scene_key != key:   # the reference rebuilds per strip; we keep it resident
+        # the reference rebuilds the BVH per strip; the scene stays resident while the world's CONTENT is the same
+        # (a slave behind HTTP gets a freshly decoded world object with every strip of a job)
+        w = info.world
+        key = (len(w.spheres), len(w.triangles), hashlib.blake2b(w.spheres.tobytes(), digest_size=16).digest(),
+               hashlib.blake2b(w.triangles.tobytes(), digest_size=16).digest())
+        if self._scene is None or self._scene_key != key:
             if self._scene:
                 self._scene.close()
             self._scene = Scene(self.device, info.world)

@@ -69,25 +69,78 @@ def world_from_json_obj(objs: list) -> World:
                  np.array(tri, dtype=TRIANGLE_DTYPE) if tri else np.zeros(0, TRIANGLE_DTYPE))
 
 
-def encode_render_info(info: RenderInfo) -> str:
-    """What the controller POSTs to a slave (controller main.rs:58-63)."""
+def world_to_json_text(world: World) -> str:
+    """The `world` array as compact JSON text, the same text json.dumps(world_to_json_obj(world)) gives (floats as the
+    shortest repr of the f32 value widened to f64), assembled with one format call per primitive."""
+    parts = []
+    if len(world.spheres):
+        s = world.spheres
+        cols = [s[k].astype(np.float64).tolist() for k in ("radius", "cx", "cy", "cz", "albedo_b", "albedo_g", "albedo_r",
+                                                            "roughness", "emission")]
+        parts += ['{"Sphere":{"radius":%r,"center":[%r,%r,%r],"node_index":0,"p_albedo_at":{"r":%r,"g":%r,"b":%r},'
+                  '"p_roughness_at":%r,"p_emission_at":%r}}' % (r, x, y, z, ar, ag, ab, ro, em)
+                  for r, x, y, z, ab, ag, ar, ro, em in zip(*cols)]
+    if len(world.triangles):
+        parts += [json.dumps(triangle_to_obj(t), separators=(",", ":")) for t in world.triangles]
+    return "[" + ",".join(parts) + "]"
+
+
+def encode_render_info(info: RenderInfo, world_text: str | None = None) -> str:
+    """What the controller POSTs to a slave (controller main.rs:47-63), fields in the struct's order (lib.rs:10-14).
+    `world_text`: world_to_json_text(info.world) from an earlier call — the controller sends the same world with every
+    strip of a job."""
     m = info.render_meta
-    return json.dumps({"division_no": int(info.division_no),
-                       "render_meta": {"divisions": int(m.divisions), "height": int(m.height), "id": str(m.id),
-                                       "width": int(m.width)},
-                       "world": world_to_json_obj(info.world)}, separators=(",", ":"))
+    if world_text is None:
+        world_text = world_to_json_text(info.world)
+    return '{"world":%s,"render_meta":{"height":%d,"width":%d,"divisions":%d,"id":"%s"},"division_no":%d}' % (
+        world_text, int(m.height), int(m.width), int(m.divisions), str(m.id), int(info.division_no))
+
+
+_WORLD_CACHE: dict = {}          # digest of the world's JSON text -> World (a job's strips all carry the same text)
+
+
+def _world_from_text(raw: bytes) -> World:
+    import hashlib
+    key = (len(raw), hashlib.blake2b(raw, digest_size=16).digest())
+    w = _WORLD_CACHE.get(key)
+    if w is None:
+        w = world_from_json_obj(json.loads(raw))
+        if len(_WORLD_CACHE) >= 4:
+            _WORLD_CACHE.pop(next(iter(_WORLD_CACHE)))
+        _WORLD_CACHE[key] = w
+    return w
 
 
 def decode_render_info(text: str | bytes, settings: RenderSettings | None = None) -> RenderInfo:
-    """What the slave's `web::Json<RenderInfo>` extractor accepts (slave main.rs:148-152)."""
-    d = json.loads(text)
+    """What the slave's `web::Json<RenderInfo>` extractor accepts (slave main.rs:148-152).  The world array is cut out
+    of the text and decoded once per distinct text (serde_json writes `world` first; this module's older form wrote
+    it last); anything else goes through the plain parser."""
+    raw = text.encode() if isinstance(text, str) else bytes(text)
+    world = None
+    i = raw.find(b'"world":[')
+    if i >= 0 and raw.count(b'"world":') == 1:
+        a = i + len(b'"world":')
+        b = raw.rfind(b'],"render_meta"')
+        if b < a:
+            b = raw.rfind(b"]") if raw.rstrip().endswith(b"]}") else -1
+        if b >= a:
+            try:
+                rest = json.loads(raw[:a] + b"null" + raw[b + 1:])
+                world = _world_from_text(raw[a:b + 1])
+                d = rest
+            except ValueError:
+                world = None
+    if world is None:
+        d = json.loads(raw)
     for k in ("world", "render_meta", "division_no"):
         if k not in d:
             raise ValueError(f"missing field `{k}`")
+    if world is None:
+        world = world_from_json_obj(d["world"])
     rm = d["render_meta"]
     meta = RenderMeta(height=int(rm["height"]), width=int(rm["width"]), divisions=int(rm["divisions"]),
                       id=uuid.UUID(rm["id"]))
-    return RenderInfo(world_from_json_obj(d["world"]), meta, int(d["division_no"]), settings or RenderSettings())
+    return RenderInfo(world, meta, int(d["division_no"]), settings or RenderSettings())
 
 
 _U8_TEXT = np.frombuffer("".join("%3d," % v for v in range(256)).encode(), dtype=np.uint8).reshape(256, 4).copy()
