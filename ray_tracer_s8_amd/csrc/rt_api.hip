@@ -54,6 +54,7 @@ std::vector<DeviceCtx*> g_ctx;
 constexpr size_t LDS_LIMIT = 160 * 1024 - 1024;   // dynamic LDS budget; 1 KiB left for the kernels' static LDS
 constexpr uint32_t RESIDENT_MAX = rtk::CHUNK;   // spheres kept wholly in LDS
 constexpr uint32_t STREAM_CHUNK = 2048;         // chunk size when streaming through LDS
+constexpr uint32_t STACK_LDS_MAX = 12;          // quantised-node kernel: stack entries per lane in LDS, deeper ones in HBM
 constexpr uint32_t TRAVERSE_MIN_TRIS = 64;      // ... or above this many triangles
 constexpr uint32_t RT_QNODES_MIN_PRIMS = 4096;   // from here up, and below this leaf density, the traversal walks the
 constexpr float RT_QNODES_MAX_DENSITY = 2.0f;    // 32-byte quantised nodes (measured, tools/crossover_q.py)
@@ -74,6 +75,8 @@ struct rt_scene {
     float4* d_tri_box = nullptr;
     float4* d_bvh = nullptr;       // rtbvh::FlatNode[]
     float4* d_trav = nullptr;      // rtbvh::TravNode[]
+    uint32_t* d_stack_ovf = nullptr;   // quantised-node kernel: stack entries beyond the LDS part, [entry][thread]
+    size_t stack_ovf_words = 0;
     uint4* d_travq = nullptr;      // rtbvh::QNode[] (quantised twin)
     float4* d_geom_r = nullptr;    // (cx,cy,cz,radius)
     rtbvh::QGrid grid;
@@ -206,7 +209,12 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     p.lds_rr_off = (uint32_t)(geom_bytes + cand_bytes + path_bytes);
     size_t rr_bytes = expanded ? (size_t)(p.chunk ? p.chunk : 1) * sizeof(float) : 0;
     p.lds_stack_off = (uint32_t)(geom_bytes + cand_bytes + path_bytes + rr_bytes);
-    size_t stack_bytes = traverse ? (size_t)(sc->bvh_depth + 1) * rtk::BLOCK * sizeof(uint32_t) : 0;
+    // stack entries a lane may need = depth + 1; the quantised-node kernel keeps at most STACK_LDS_MAX of them in LDS
+    const uint32_t stack_need = sc->bvh_depth + 1;
+    static const uint32_t stack_lds_max = [] { const char* e = getenv("RT_STACK_LDS"); return e && atoi(e) > 0 ? (uint32_t)atoi(e) : STACK_LDS_MAX; }();
+    const uint32_t stack_lds = qnodes ? std::min(stack_need, stack_lds_max) : stack_need;
+    p.stack_lds = stack_lds;
+    size_t stack_bytes = traverse ? (size_t)stack_lds * rtk::BLOCK * sizeof(uint32_t) : 0;
     size_t lds = geom_bytes + cand_bytes + path_bytes + rr_bytes + stack_bytes;
     if (lds > LDS_LIMIT) return fail(RT_ERR_LIMIT, "LDS budget exceeded (scene chunk + path stack)");
     fill_camera(rq, p);
@@ -272,6 +280,23 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     uint32_t blocks = (uint32_t)sc->ctx->n_cu * (uint32_t)per_cu;
     const uint32_t useful = (p.n_tiles + 3) / 4;                 // a wave needs at least one tile
     if (blocks > useful) blocks = useful ? useful : 1;
+    p.ovf_stride = blocks * (uint32_t)rtk::BLOCK;
+    p.stack_ovf = nullptr;
+    if (traverse && stack_need > stack_lds) {
+        const size_t words = (size_t)(stack_need - stack_lds) * p.ovf_stride;
+        if (words > sc->stack_ovf_words) {
+            if (sc->d_stack_ovf) {
+                HIPCHK(hipStreamSynchronize(stream));              // launches in flight may still use the old area
+                HIPCHK(hipStreamSynchronize(sc->ctx->stream));
+                (void)hipFree(sc->d_stack_ovf);
+                sc->d_stack_ovf = nullptr;
+                sc->stack_ovf_words = 0;
+            }
+            HIPCHK(hipMalloc(&sc->d_stack_ovf, words * sizeof(uint32_t)));
+            sc->stack_ovf_words = words;
+        }
+        p.stack_ovf = sc->d_stack_ovf;
+    }
     dim3 grid(blocks), block(rtk::BLOCK);
     EvPair ev;
     int rc = get_events(sc, ev);
@@ -667,6 +692,7 @@ RT_API void rt_scene_destroy(rt_scene* sc) {
     (void)hipFree(sc->d_bvh);
     (void)hipFree(sc->d_trav);
     (void)hipFree(sc->d_travq);
+    (void)hipFree(sc->d_stack_ovf);
     (void)hipFree(sc->d_geom_r);
     (void)hipFree(sc->d_leaf_of);
     (void)hipFree(sc->d_counters);

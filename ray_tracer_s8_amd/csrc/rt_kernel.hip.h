@@ -111,6 +111,9 @@ struct KParams {
     const float4* geom_r;        // [n_sph] (cx,cy,cz, radius): exact Sphere::aabb on the fly for leaf validation
     float q_base[3], q_step[3], q_rstep[3];   // grid: coordinate = q_base + q * q_step; q_rstep = 1 / q_step
     uint32_t root_ref;           // root reference (LEAF_BIT | prim when the tree is a single leaf)
+    uint32_t stack_lds;          // quantised-node kernel: stack entries per lane kept in LDS, deeper ones go to stack_ovf
+    uint32_t ovf_stride;         //   threads in the grid (stride of the overflow area)
+    uint32_t* stack_ovf;         //   [entries beyond stack_lds][ovf_stride]
     uint32_t refill_eighths;     // traversal: finished lanes are refilled once <= this many eighths of the live lanes still walk
     const float4* bvh_nodes;     // [2*n_nodes]: (lo.xyz, parent as bits) (hi.xyz, -) — rt_bvh.h FlatNode
     const uint32_t* leaf_of;     // [n_sph+n_tri] primitive -> leaf node index (= DFS rank)
@@ -706,6 +709,19 @@ __global__ __launch_bounds__(BLOCK, ISECT == 3 ? RT_MINWAVES_QTRAV : ISECT == 2 
                 }
                 t_cnt = 0;
             };
+            // Per-lane stack.  The exact-node kernel keeps all of it in LDS ((depth + 1) KiB per workgroup); the quantised
+            // kernel (large scenes, deep trees) keeps p.stack_lds entries there and the rare deeper ones in HBM, so
+            // that the tree's depth does not take the CU's LDS away from its occupancy.
+            auto push = [&](uint32_t v) {
+                if (!QNODES || t_sp < p.stack_lds) lstack[t_sp * BLOCK + tid] = v;
+                else p.stack_ovf[(size_t)(t_sp - p.stack_lds) * p.ovf_stride + (blockIdx.x * BLOCK + tid)] = v;
+                t_sp++;
+            };
+            auto pop = [&]() -> uint32_t {
+                --t_sp;
+                if (!QNODES || t_sp < p.stack_lds) return lstack[t_sp * BLOCK + tid];
+                return p.stack_ovf[(size_t)(t_sp - p.stack_lds) * p.ovf_stride + (blockIdx.x * BLOCK + tid)];
+            };
             for (;;) {
                 const uint32_t walking = (uint32_t)__builtin_popcountll(__ballot(in_trav));
                 const uint32_t live = (uint32_t)__builtin_popcountll(__ballot(true));
@@ -736,7 +752,7 @@ __global__ __launch_bounds__(BLOCK, ISECT == 3 ? RT_MINWAVES_QTRAV : ISECT == 2 
                         if (t_sp == 0) {
                             in_trav = false;                 // candidates are tested together after the walk
                         } else {
-                            t_ref = lstack[--t_sp * BLOCK + tid];
+                            t_ref = pop();
                         }
                     } else {
                         bool hl, hr;
@@ -791,14 +807,14 @@ __global__ __launch_bounds__(BLOCK, ISECT == 3 ? RT_MINWAVES_QTRAV : ISECT == 2 
                             cr = __float_as_uint(n1.w);
                         }
                         if (hl) {
-                            if (hr) lstack[t_sp++ * BLOCK + tid] = cr;   // right subtree after the whole left subtree
+                            if (hr) push(cr);                            // right subtree after the whole left subtree
                             t_ref = cl;
                         } else if (hr) {
                             t_ref = cr;
                         } else if (t_sp == 0) {
                             in_trav = false;
                         } else {
-                            t_ref = lstack[--t_sp * BLOCK + tid];
+                            t_ref = pop();
                         }
                     }
                 }
