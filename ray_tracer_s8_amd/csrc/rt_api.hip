@@ -201,19 +201,37 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     p.path32 = (sc->n_sph + sc->n_tri) > 65536u ? 1u : 0u;
     size_t geom_bytes = traverse ? 0 : (size_t)(p.chunk ? p.chunk : 1) * sizeof(float4);
     p.lds_cand_off = (uint32_t)geom_bytes;
-    size_t cand_bytes = traverse ? (size_t)(qnodes ? rtk::MAXL : rtk::MAXL_EXACT) * rtk::BLOCK * sizeof(uint32_t)
+    size_t path_bytes = (size_t)p.depth * rtk::BLOCK * (p.path32 ? 4 : 2);
+    // ---- LDS plan of a traversal launch.  Occupancy is worth more than long leaf lists (c3: 6 workgroups per CU with
+    // 7 slots +1.5 % over 5 with 8; c5: 5 with 5 slots +7.5 % over 4 with 8), and an uncapped stack more than either
+    // (the HBM-overflow test on every push / pop costs 6...10 %).  So: the target number of workgroups per CU follows
+    // from the kernel's registers (exact nodes 6, quantised 5).  The exact-node kernel has 7 slots, fixed; the quantised
+    // kernel's lists shrink from MAXL down to MINL slots to reach its target, and a quantised walk whose whole stack still
+    // does not fit takes the capped-stack kernel.
+    const uint32_t stack_need = sc->bvh_depth + 1;
+    uint32_t maxl = qnodes ? (uint32_t)rtk::MAXL : (uint32_t)rtk::MAXL_EXACT, stack_lds = stack_need;
+    bool capped = false;
+    if (traverse && qnodes) {
+        const size_t per_wg = (160u * 1024u - 4096u) / 5u - 256u;     // 4 KiB of slack, 256 B static LDS
+        const size_t fixed = path_bytes + (size_t)stack_need * rtk::BLOCK * sizeof(uint32_t);
+        const size_t slot = (size_t)rtk::BLOCK * sizeof(uint32_t);
+        if (fixed + (size_t)rtk::MINL * slot <= per_wg) {
+            maxl = (uint32_t)std::min<size_t>((size_t)rtk::MAXL, (per_wg - fixed) / slot);
+        } else {
+            static const uint32_t cap = [] { const char* e = getenv("RT_STACK_LDS"); return e && atoi(e) > 0 ? (uint32_t)atoi(e) : STACK_LDS_MAX; }();
+            capped = stack_need > cap;
+            stack_lds = std::min(stack_need, cap);
+        }
+    }
+    p.maxl = maxl;
+    p.stack_lds = stack_lds;
+    size_t cand_bytes = traverse ? (size_t)maxl * rtk::BLOCK * sizeof(uint32_t)
                                  : (size_t)rtk::MAXC * rtk::BLOCK * sizeof(uint16_t);
     p.lds_path_off = (uint32_t)(geom_bytes + cand_bytes);
-    size_t path_bytes = (size_t)p.depth * rtk::BLOCK * (p.path32 ? 4 : 2);
     const bool expanded = !traverse && sc->expanded && !(rq->flags & RT_FLAG_OC_BROAD_PHASE);
     p.lds_rr_off = (uint32_t)(geom_bytes + cand_bytes + path_bytes);
     size_t rr_bytes = expanded ? (size_t)(p.chunk ? p.chunk : 1) * sizeof(float) : 0;
     p.lds_stack_off = (uint32_t)(geom_bytes + cand_bytes + path_bytes + rr_bytes);
-    // stack entries a lane may need = depth + 1; the quantised-node kernel keeps at most STACK_LDS_MAX of them in LDS
-    const uint32_t stack_need = sc->bvh_depth + 1;
-    static const uint32_t stack_lds_max = [] { const char* e = getenv("RT_STACK_LDS"); return e && atoi(e) > 0 ? (uint32_t)atoi(e) : STACK_LDS_MAX; }();
-    const uint32_t stack_lds = qnodes ? std::min(stack_need, stack_lds_max) : stack_need;
-    p.stack_lds = stack_lds;
     size_t stack_bytes = traverse ? (size_t)stack_lds * rtk::BLOCK * sizeof(uint32_t) : 0;
     size_t lds = geom_bytes + cand_bytes + path_bytes + rr_bytes + stack_bytes;
     if (lds > LDS_LIMIT) return fail(RT_ERR_LIMIT, "LDS budget exceeded (scene chunk + path stack)");
@@ -270,13 +288,14 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
 
     // persistent grid: as many workgroups as the chip holds at this LDS/VGPR budget
     int per_cu = 0;
-    const rtk::KernelFn kern = traverse ? rtk::kernel_traverse(qnodes) : rtk::kernel_linear(streamed, expanded);
+    const rtk::KernelFn kern = traverse ? rtk::kernel_traverse(qnodes ? (capped ? 2 : 1) : 0) : rtk::kernel_linear(streamed, expanded);
     HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, rtk::BLOCK, lds));
     if (per_cu < 1) per_cu = 1;
     static const bool verbose = getenv("RT_VERBOSE") != nullptr;
     if (verbose)
-        fprintf(stderr, "[rt] engine %d  lds %zu B  workgroups/CU %d  bvh depth %u  leaf density %.3f  prims %u\n",
-                traverse ? (qnodes ? 3 : 2) : (streamed ? 1 : 0), lds, per_cu, sc->bvh_depth, sc->leaf_density, n_prims);
+        fprintf(stderr, "[rt] engine %d%s  lds %zu B  workgroups/CU %d  leaf slots %u  bvh depth %u  leaf density %.3f  prims %u\n",
+                traverse ? (qnodes ? 3 : 2) : (streamed ? 1 : 0), capped ? " (capped stack)" : "", lds, per_cu, maxl,
+                sc->bvh_depth, sc->leaf_density, n_prims);
     uint32_t blocks = (uint32_t)sc->ctx->n_cu * (uint32_t)per_cu;
     const uint32_t useful = (p.n_tiles + 3) / 4;                 // a wave needs at least one tile
     if (blocks > useful) blocks = useful ? useful : 1;
@@ -429,8 +448,8 @@ static int ensure_ctx(DeviceCtx* c) {
         for (int expanded = 0; expanded < 2; expanded++)
             HIPCHK(hipFuncSetAttribute((const void*)rtk::kernel_linear(streamed != 0, expanded != 0),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
-    for (int quantised = 0; quantised < 2; quantised++)
-        HIPCHK(hipFuncSetAttribute((const void*)rtk::kernel_traverse(quantised != 0),
+    for (int variant = 0; variant < 3; variant++)
+        HIPCHK(hipFuncSetAttribute((const void*)rtk::kernel_traverse(variant),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
     hipStream_t st = nullptr, cs = nullptr;
     HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));

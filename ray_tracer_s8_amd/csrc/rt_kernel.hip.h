@@ -53,8 +53,8 @@ constexpr int TRAV_STACK = 64;   // traversal stack entries per lane (host falls
 #ifndef RT_MAXL
 #define RT_MAXL 8
 #endif
-#ifndef RT_MAXL_EXACT           // exact-node kernel: 7 KiB of leaf lists lets six of its workgroups share a CU's LDS
-#define RT_MAXL_EXACT 7
+#ifndef RT_MINL                 // the host may shrink the leaf lists down to this many slots to fit one more workgroup per CU
+#define RT_MINL 4
 #endif
 #ifndef RT_STEPS_PER_CHECK
 #define RT_STEPS_PER_CHECK 8
@@ -66,7 +66,8 @@ constexpr int TRAV_STACK = 64;   // traversal stack entries per lane (host falls
 #define RT_REFILL_EIGHTHS 3
 #endif
 constexpr int MAXL = RT_MAXL;    // leaf-candidate slots per lane in traversal mode (flushed when full)
-constexpr int MAXL_EXACT = RT_MAXL_EXACT;
+constexpr int MINL = RT_MINL;
+constexpr int MAXL_EXACT = 7;
 constexpr uint32_t LEAF_BIT = 0x80000000u;
 
 struct StripDesc {
@@ -111,7 +112,8 @@ struct KParams {
     const float4* geom_r;        // [n_sph] (cx,cy,cz, radius): exact Sphere::aabb on the fly for leaf validation
     float q_base[3], q_step[3], q_rstep[3];   // grid: coordinate = q_base + q * q_step; q_rstep = 1 / q_step
     uint32_t root_ref;           // root reference (LEAF_BIT | prim when the tree is a single leaf)
-    uint32_t stack_lds;          // quantised-node kernel: stack entries per lane kept in LDS, deeper ones go to stack_ovf
+    uint32_t maxl;               // traversal: leaf-list slots per lane (MINL..MAXL)
+    uint32_t stack_lds;          // capped quantised-node kernel: stack entries per lane kept in LDS, deeper ones go to stack_ovf
     uint32_t ovf_stride;         //   threads in the grid (stride of the overflow area)
     uint32_t* stack_ovf;         //   [entries beyond stack_lds][ovf_stride]
     uint32_t refill_eighths;     // traversal: finished lanes are refilled once <= this many eighths of the live lanes still walk
@@ -449,11 +451,14 @@ __device__ __forceinline__ const T& at32(const T* __restrict__ base, uint32_t i)
 // 32-byte nodes whose boxes are rounded outwards onto a 16-bit grid, every reached leaf being validated with the
 // reference's exact own-leaf AABB test.
 template <int ISECT, bool EXPANDED>
-__global__ __launch_bounds__(BLOCK, ISECT == 3 ? RT_MINWAVES_QTRAV : ISECT == 2 ? RT_MINWAVES_TRAV : RT_MINWAVES) void rt_tile_kernel(const KParams p) {
+__global__ __launch_bounds__(BLOCK, ISECT >= 3 ? RT_MINWAVES_QTRAV : ISECT == 2 ? RT_MINWAVES_TRAV : RT_MINWAVES) void rt_tile_kernel(const KParams p) {
     constexpr bool STREAMED = (ISECT == 1);
     constexpr bool TRAVERSE = (ISECT >= 2);
-    constexpr bool QNODES = (ISECT == 3);            // traversal over 32-byte conservatively quantised nodes
-    constexpr uint32_t ML = (ISECT == 2) ? (uint32_t)MAXL_EXACT : (uint32_t)MAXL;   // leaf-list slots per lane
+    constexpr bool QNODES = (ISECT == 3 || ISECT == 4);   // traversal over 32-byte conservatively quantised nodes
+    constexpr bool CAPPED = (ISECT == 4);            // ... whose stack keeps p.stack_lds entries in LDS, deeper ones in HBM
+    // leaf-list slots per lane: the exact-node kernel's are fixed (7 KiB lets six of its workgroups share a CU's LDS on
+    // c3-class trees; a run-time count cost it 1 %), the quantised kernels' are chosen by the host's LDS plan
+    const uint32_t ML = QNODES ? p.maxl : (uint32_t)MAXL_EXACT;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     float4* lgeom = reinterpret_cast<float4*>(lds_raw);          // pair layout, see KParams::geom_pk / geom_px
     const float* lgeomf = reinterpret_cast<const float*>(lds_raw);
@@ -713,13 +718,13 @@ __global__ __launch_bounds__(BLOCK, ISECT == 3 ? RT_MINWAVES_QTRAV : ISECT == 2 
             // kernel (large scenes, deep trees) keeps p.stack_lds entries there and the rare deeper ones in HBM, so
             // that the tree's depth does not take the CU's LDS away from its occupancy.
             auto push = [&](uint32_t v) {
-                if (!QNODES || t_sp < p.stack_lds) lstack[t_sp * BLOCK + tid] = v;
+                if (!CAPPED || t_sp < p.stack_lds) lstack[t_sp * BLOCK + tid] = v;
                 else p.stack_ovf[(size_t)(t_sp - p.stack_lds) * p.ovf_stride + (blockIdx.x * BLOCK + tid)] = v;
                 t_sp++;
             };
             auto pop = [&]() -> uint32_t {
                 --t_sp;
-                if (!QNODES || t_sp < p.stack_lds) return lstack[t_sp * BLOCK + tid];
+                if (!CAPPED || t_sp < p.stack_lds) return lstack[t_sp * BLOCK + tid];
                 return p.stack_ovf[(size_t)(t_sp - p.stack_lds) * p.ovf_stride + (blockIdx.x * BLOCK + tid)];
             };
             for (;;) {
@@ -1091,6 +1096,6 @@ __global__ __launch_bounds__(BLOCK, ISECT == 3 ? RT_MINWAVES_QTRAV : ISECT == 2 
 // The kernels are instantiated in rt_kernels_lin.hip / rt_kernels_trav.hip; the host side (rt_api.hip) gets them here.
 using KernelFn = void (*)(const KParams);
 KernelFn kernel_linear(bool streamed, bool expanded);
-KernelFn kernel_traverse(bool quantised);
+KernelFn kernel_traverse(int variant);   // 0: exact nodes, 1: quantised nodes, 2: quantised nodes with the capped LDS stack
 
 }  // namespace rtk

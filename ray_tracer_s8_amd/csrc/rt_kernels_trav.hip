@@ -1,8 +1,11 @@
-// Device code of the BVH-traversal engines (ISECT 2: exact 64-byte nodes, 3: quantised 32-byte nodes).  Its own
+// Device code of the BVH-traversal engines (ISECT 2: exact 64-byte nodes, 3: quantised 32-byte nodes, 4: the same
+// with a capped LDS stack).  Its own
 // translation unit: compiled with -fno-slp-vectorize (build.py) — packed FP32 pairs made by the SLP vectoriser in the
 // ray-generation / shading code cost these kernels 1.5 % (register pairs, v_pk_mov), while the linear kernels gain 3 %.
 #include "rt_kernel.hip.h"
 
 namespace rtk {
-KernelFn kernel_traverse(bool quantised) { return quantised ? rt_tile_kernel<3, false> : rt_tile_kernel<2, false>; }
+KernelFn kernel_traverse(int variant) {
+    return variant == 2 ? rt_tile_kernel<4, false> : variant == 1 ? rt_tile_kernel<3, false> : rt_tile_kernel<2, false>;
+}
 }  // namespace rtk
