@@ -42,7 +42,7 @@ constexpr int BLOCK = 256;       // 4 waves
 #ifndef RT_MINWAVES_TRAV
 #define RT_MINWAVES_TRAV 6       // exact-node kernel: 80 VGPRs, 2 spill slots outside the loops; c3 +1 %, c4 +2 % over 5
 #endif
-#ifndef RT_MINWAVES_QTRAV       // quantised-node traversal: 114 VGPRs; 5 waves/SIMD spills 41 of them (slower)
+#ifndef RT_MINWAVES_QTRAV       // quantised-node kernels: the bound is 4, the 90-92 VGPRs they take allow 5 waves/SIMD
 #define RT_MINWAVES_QTRAV 4
 #endif
 constexpr int MAXC = RT_MAXC;    // candidate list slots per lane (per chunk)
@@ -62,12 +62,9 @@ constexpr int TRAV_STACK = 64;   // traversal stack entries per lane (host falls
 #ifndef RT_STEPS_PER_CHECK_Q    // quantised-node kernel (large scenes, long walks): c5 +1 % over 8
 #define RT_STEPS_PER_CHECK_Q 16
 #endif
-#ifndef RT_REFILL_EIGHTHS
-#define RT_REFILL_EIGHTHS 3
-#endif
 constexpr int MAXL = RT_MAXL;    // leaf-candidate slots per lane in traversal mode (flushed when full)
 constexpr int MINL = RT_MINL;
-constexpr int MAXL_EXACT = 7;
+constexpr int MAXL_EXACT = 7;     // exact-node kernel: fixed (see the kernel)
 constexpr uint32_t LEAF_BIT = 0x80000000u;
 
 struct StripDesc {
