@@ -99,8 +99,8 @@ enum {
      * reference's result bit for bit; these force one or the other (A/B runs, tests). */
     RT_FLAG_BVH_TRAVERSE = 1u << 4,
     RT_FLAG_LINEAR_SCAN = 1u << 5,
-    /* Traversal node format.  Default: the exact 64-byte nodes up to RT_QNODES_MIN_PRIMS primitives, the
-     * 32-byte conservatively quantised nodes (exact validation at the leaves) above that.  Identical images;
+    /* Traversal node format.  Default: the exact 64-byte nodes below 4096 primitives, the
+     * 32-byte conservatively quantised nodes (exact validation at the leaves) from there up.  Identical images;
      * these force one or the other (A/B runs, tests). */
     RT_FLAG_EXACT_NODES = 1u << 6,
     RT_FLAG_QUANT_NODES = 1u << 7

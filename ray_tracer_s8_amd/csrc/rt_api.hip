@@ -56,8 +56,7 @@ constexpr uint32_t RESIDENT_MAX = rtk::CHUNK;   // spheres kept wholly in LDS
 constexpr uint32_t STREAM_CHUNK = 2048;         // chunk size when streaming through LDS
 constexpr uint32_t STACK_LDS_MAX = 12;          // quantised-node kernel: stack entries per lane in LDS, deeper ones in HBM
 constexpr uint32_t TRAVERSE_MIN_TRIS = 64;      // ... or above this many triangles
-constexpr uint32_t RT_QNODES_MIN_PRIMS = 4096;   // from here up, and below this leaf density, the traversal walks the
-constexpr float RT_QNODES_MAX_DENSITY = 2.0f;    // 32-byte quantised nodes (measured, tools/crossover_q.py)
+constexpr uint32_t RT_QNODES_MIN_PRIMS = 4096;   // from here up the traversal walks the 32-byte quantised nodes (tools/crossover_q.py)
 constexpr uint32_t TRAVERSE_MIN_PRIMS = 384;    // above this many primitives the BVH-traversal engine is the default (measured crossover, tools/crossover.py: 0.92 at 256, 1.11 at 512)
 
 }  // namespace
@@ -189,12 +188,12 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     // (the linear engines test every triangle's box per segment: meshes switch to the tree much earlier)
     const bool traverse = trav_ok && ((rq->flags & RT_FLAG_BVH_TRAVERSE) || n_prims > TRAVERSE_MIN_PRIMS ||
                                       sc->n_tri > TRAVERSE_MIN_TRIS);
-    // node format: the halved gather footprint pays once the 64-byte node array is far larger than the per-CU
-    // caches and the rays reach few leaves (c5: +24 %); small or dense scenes are bound by the leaf tests, where
-    // the exact-node kernel's 5 waves/SIMD win (c3: +3 %, dense fields: +10 %).  tools/crossover_q.py, DESIGN.md 4.7
+    // node format: from RT_QNODES_MIN_PRIMS primitives up the 32-byte quantised nodes (half the gather footprint, and an
+    // LDS plan that keeps five workgroups per CU whatever the tree's depth): +14 % on sparse fields of every size, +17...29 %
+    // on dense fields of 32 768+ spheres, within 2.5 % either way in between; below it the exact-node kernel's six
+    // waves per SIMD win on the headline scene (c3 +1.5 %).  tools/crossover_q.py, DESIGN.md 4.7
     const bool qnodes = traverse && sc->quant_ok && !(rq->flags & RT_FLAG_EXACT_NODES) &&
-                        ((rq->flags & RT_FLAG_QUANT_NODES) ||
-                         (n_prims >= RT_QNODES_MIN_PRIMS && sc->leaf_density < RT_QNODES_MAX_DENSITY));
+                        ((rq->flags & RT_FLAG_QUANT_NODES) || n_prims >= RT_QNODES_MIN_PRIMS);
     const bool streamed = !traverse && sc->n_sph_pad > RESIDENT_MAX;
     p.chunk = traverse ? 0 : (streamed ? STREAM_CHUNK : sc->n_sph_pad);
     p.n_chunks = p.chunk ? (sc->n_sph_pad + p.chunk - 1) / p.chunk : 0;
