@@ -42,6 +42,9 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "c5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--overlap", type=int, default=0, metavar="N", help="NOT the contract's measurement: consecutive steps go to N streams "
+                    "with N output buffers, so that a launch starts filling the GPU while the previous one drains its "
+                    "tail; per-launch HIP-event times then include queueing and the roofline object is not comparable")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-buffer (PCIe-inclusive) pass: profiling runs "
                     "then see whole-frame launches only")
     ap.add_argument("--cpu-scale", type=int, default=1, help="CPU baseline renders the frame at 1/scale resolution")
@@ -146,7 +149,20 @@ def main():
     # seed (frames), every other field is the frame's (rt_scene_render_tiles_device)
     batches = [(reqs, out_ptrs)]
 
+    step_no = [0]
+    if args.overlap:
+        lanes, keep = [(stream, out_ptrs)], []
+        for _ in range(max(args.overlap, 2) - 1):
+            ob, sb = torch.empty_like(out), torch.cuda.Stream()
+            keep.append((ob, sb))
+            lanes.append((sb.cuda_stream, [ob.data_ptr() + i * strip_bytes for i in range(len(reqs))]))
+
     def step():
+        if args.overlap:
+            st_i, ptrs_i = lanes[step_no[0] % len(lanes)]
+            step_no[0] += 1
+            scene.render_tiles_device(reqs, ptrs_i, strip_bytes, st_i)
+            return
         for rs, ps in batches:
             scene.render_tiles_device(rs, ps, strip_bytes, stream)
 
@@ -237,6 +253,7 @@ def main():
                            "per-lane traversal of the reference BVH (exact nodes)",
                            "per-lane traversal of the reference BVH (quantised nodes, exact leaf validation)"][st.engine],
                 "flags": args.flags,
+                "overlapped_steps": bool(args.overlap),
                 "pcie_inclusive": pcie,
                 "broad_candidates_per_segment": float(st.broad_candidates) / max(float(st.ray_segments), 1.0),
                 "exact_fallbacks": int(st.exact_fallbacks),

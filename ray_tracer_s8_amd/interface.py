@@ -157,12 +157,15 @@ class Scene:
                             stream: int = 0):
         """Batched, asynchronous, device-resident output (rt_scene_render_tiles_device)."""
         n = len(reqs)
-        cache = getattr(self, "_batch_cache", None)
+        caches = self.__dict__.setdefault("_batch_cache", {})
         key = (id(reqs), tuple(d_out_ptrs))
-        if cache is None or cache[0] != key:
+        cache = caches.get(key)
+        if cache is None:
+            if len(caches) >= 4:
+                caches.clear()
             arr = (TileRequest * n)(*reqs)
             po = (C.c_void_p * n)(*d_out_ptrs)
-            self._batch_cache = cache = (key, arr, po)
+            caches[key] = cache = (key, arr, po)
         _abi.check(self._lib.rt_scene_render_tiles_device(self._h, cache[1], n, cache[2], out_len_each, None,
                                                           C.c_void_p(stream) if stream else None),
                    "rt_scene_render_tiles_device")
