@@ -490,8 +490,7 @@ __global__ __launch_bounds__(BLOCK, ISECT >= 3 ? RT_MINWAVES_QTRAV : ISECT == 2 
     uint64_t tile_seed = 0;
     // ---- per-lane pixel state
     bool have_pixel = false, retired = false, need_ray = false;
-    uint32_t px = 0, pyl = 0, strip = 0;
-    float xf = 0.f, ycf = 0.f;
+    uint32_t px = 0, pyg = 0, strip = 0;      // pixel column, GLOBAL row (main.rs:66-68), strip index in the batch
     Rng rng = {0, 0, 0, 0};
     float sum_r = 0.f, sum_g = 0.f, sum_b = 0.f;
     uint32_t s_idx = 0;          // samples finished
@@ -574,11 +573,9 @@ __global__ __launch_bounds__(BLOCK, ISECT >= 3 ? RT_MINWAVES_QTRAV : ISECT == 2 
                     const uint32_t x = tile_x0 + (pidx & ((1u << p.tile_wlog2) - 1u)), y = tile_y0 + (pidx >> p.tile_wlog2);
                     if (x < p.W && y < p.Hs) {
                         px = x;
-                        pyl = y;
                         strip = tile_strip;
                         const uint32_t yg = tile_yg0 + y;                         // main.rs:66-68
-                        xf = (float)x;
-                        ycf = (float)(p.H - yg - 1);                              // main.rs:71
+                        pyg = yg;
                         rng = seed_pixel(tile_seed, (uint64_t)yg * p.W + x);
                         sum_r = sum_g = sum_b = 0.f;
                         s_idx = 0;
@@ -621,8 +618,8 @@ __global__ __launch_bounds__(BLOCK, ISECT >= 3 ? RT_MINWAVES_QTRAV : ISECT == 2 
             } else {
                 LCOUNT(4);
                 const V3 offset = mk(x1 * p.lens_radius, x2 * p.lens_radius, 0.0f);
-                const float u = (xf + gen_range_01(rng)) / p.u_den;
-                const float v = (ycf + gen_range_01(rng)) / p.v_den;
+                const float u = ((float)px + gen_range_01(rng)) / p.u_den;
+                const float v = ((float)(p.H - pyg - 1) + gen_range_01(rng)) / p.v_den;   // camera row, main.rs:71
                 const V3 dir0 = normalize_or_zero(llc + u * hor + v * ver - corg);
                 const V3 d1 = normalize(dir0);                     // Ray::new re-normalises (ray.rs:134)
                 const V3 focal_point = corg + p.focus_distance * d1;
@@ -1070,7 +1067,7 @@ __global__ __launch_bounds__(BLOCK, ISECT >= 3 ? RT_MINWAVES_QTRAV : ISECT == 2 
                     float r = __builtin_sqrtf(sum_r / p.spp_f);
                     float g = __builtin_sqrtf(sum_g / p.spp_f);
                     float b = __builtin_sqrtf(sum_b / p.spp_f);
-                    size_t oidx = ((size_t)pyl * p.W + px) * 3;
+                    size_t oidx = ((size_t)(pyg - p.strips[strip].y0) * p.W + px) * 3;      // row within the strip
                     uint8_t* orgb = p.strips[strip].rgb;
                     orgb[oidx + 0] = f32_as_u8(r * 255.999f);
                     orgb[oidx + 1] = f32_as_u8(g * 255.999f);
