@@ -505,3 +505,40 @@ def test_more_than_65536_primitives(ndev, oracle, flags):
     rq = _abi.default_request(width=96, height=54, divisions=1, spp=2, max_bounces=6, seed=77)
     st = _compare(oracle, rq, sph, tri, flags=flags)
     assert st.engine == {0: 3, _abi.RT_FLAG_EXACT_NODES: 2, _abi.RT_FLAG_LINEAR_SCAN: 1}[flags]
+
+
+def test_concurrent_host_threads_share_device_and_scene(ndev):
+    """C-ABI threading contract: calls on one device (own scenes or one shared scene) serialise and stay correct.
+    Four threads render different strips at once, each through its own scene and through one shared scene."""
+    import threading
+    sph, rq = _small("c3", 256, 144, spp=2, div=8)
+    with rt.Scene(0, rt.World(sph)) as ref_sc:
+        want = []
+        for k in range(8):
+            r = rq.copy(); r.division_no = k
+            want.append(ref_sc.render_tile(r)[0].copy())
+    shared = rt.Scene(0, rt.World(sph))
+    errors = []
+
+    def work(tid):
+        try:
+            own = rt.Scene(0, rt.World(sph))
+            for it in range(6):
+                k = (tid * 3 + it) % 8
+                r = rq.copy(); r.division_no = k
+                a = own.render_tile(r)[0]
+                b = shared.render_tile(r)[0]
+                outs, _, _ = shared.render_tiles([r, r])
+                if not (np.array_equal(a, want[k]) and np.array_equal(b, want[k]) and np.array_equal(outs[1], want[k])):
+                    errors.append((tid, it, k))
+            own.close()
+        except Exception as e:          # pragma: no cover
+            errors.append((tid, repr(e)))
+
+    ths = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    shared.close()
+    assert not errors, errors
