@@ -251,7 +251,8 @@ def main():
                 "segments_per_primary": segs / prim,
                 "engine": ["linear scan, scene resident in LDS", "linear scan, scene streamed through LDS",
                            "per-lane traversal of the reference BVH (exact nodes)",
-                           "per-lane traversal of the reference BVH (quantised nodes, exact leaf validation)"][st.engine],
+                           "per-lane traversal of the reference BVH (quantised nodes, exact leaf validation)",
+                           "per-lane traversal of the reference BVH (exact nodes resident in LDS)"][st.engine],
                 "flags": args.flags,
                 "overlapped_steps": bool(args.overlap),
                 "pcie_inclusive": pcie,

@@ -103,7 +103,10 @@ enum {
      * 32-byte conservatively quantised nodes (exact validation at the leaves) from there up.  Identical images;
      * these force one or the other (A/B runs, tests). */
     RT_FLAG_EXACT_NODES = 1u << 6,
-    RT_FLAG_QUANT_NODES = 1u << 7
+    RT_FLAG_QUANT_NODES = 1u << 7,
+    /* A tree whose exact nodes fit a CU's LDS (about 1000 primitives) is walked from an LDS-resident copy by default;
+     * this flag keeps the nodes in HBM / L2 (A/B runs, tests).  Identical images. */
+    RT_FLAG_NO_LDS_TREE = 1u << 8
 };
 
 typedef struct rt_tile_request {
@@ -140,7 +143,8 @@ typedef struct rt_tile_stats {
     uint32_t n_launches;        /* kernel launches issued by this call                        */
     uint32_t engine;            /* closest-hit engine of the last launch: 0 linear scan (scene resident
                                    in LDS), 1 linear scan (scene streamed through LDS), 2 BVH traversal (exact nodes),
-                                   3 BVH traversal (quantised nodes + exact leaf validation) */
+                                   3 BVH traversal (quantised nodes + exact leaf validation),
+                                   4 BVH traversal, exact nodes resident in LDS */
     uint32_t broad_form;        /* linear engines: 0 = oc form, 1 = expanded form   */
 } rt_tile_stats;
 

@@ -31,6 +31,7 @@ RT_FLAG_BVH_TRAVERSE = 16
 RT_FLAG_LINEAR_SCAN = 32
 RT_FLAG_EXACT_NODES = 64
 RT_FLAG_QUANT_NODES = 128
+RT_FLAG_NO_LDS_TREE = 256
 RT_MAX_BOUNCES = 62
 
 # numpy dtypes with the exact layout of rt_sphere / rt_triangle (no padding)

@@ -81,7 +81,7 @@ struct rt_scene {
     rtbvh::QGrid grid;
     float leaf_density = 0.f;      // sum of primitive box areas / scene box area (node-format heuristic)
     bool quant_ok = false;         // quantised walk usable and worthwhile (grid step small against the primitives)
-    uint32_t root_ref = 0, bvh_depth = 0;
+    uint32_t root_ref = 0, bvh_depth = 0, n_internal = 0;
     uint32_t* d_leaf_of = nullptr;
     float bvh_build_ms = 0.f;
     unsigned long long* d_counters = nullptr;   // [0..2] stats, [4 + slot] tile queues
@@ -194,6 +194,24 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     // waves per SIMD win on the headline scene (c3 +1.5 %).  tools/crossover_q.py, DESIGN.md 4.7
     const bool qnodes = traverse && sc->quant_ok && !(rq->flags & RT_FLAG_EXACT_NODES) &&
                         ((rq->flags & RT_FLAG_QUANT_NODES) || n_prims >= RT_QNODES_MIN_PRIMS);
+    // LDS-resident tree (engine 4, kernel variant 3): the exact 64-byte nodes of a small scene staged into LDS by one
+    // 1024-thread workgroup per CU, 16-bit references / stack / leaf lists, materials and geometry alongside while they
+    // fit.  RT_FLAG_NO_LDS_TREE forces the L2-gather kernel (A/B runs, tests).
+    static const bool ltree_env = [] { const char* e = getenv("RT_LDS_TREE"); return !e || atoi(e) != 0; }();
+    bool ltree = false;
+    size_t lt_mat = 0, lt_emis = 0, lt_geom = 0;      // bytes staged besides the nodes (0 = stays in HBM)
+    const size_t lt_lane = ((size_t)rtk::MAXL_LTREE + (size_t)(rq->max_bounces + 1) + (size_t)(sc->bvh_depth + 2)) * sizeof(uint16_t);
+    if (traverse && !qnodes && ltree_env && !(rq->flags & RT_FLAG_NO_LDS_TREE) && sc->n_internal > 0 && n_prims <= 0x7fffu) {
+        const size_t fixed = ((size_t)sc->n_internal + 1) * 64 + lt_lane * rtk::LTREE_BLOCK;   // + the DONE node
+        if (fixed <= LDS_LIMIT) {
+            ltree = true;
+            static const int extras = [] { const char* e = getenv("RT_LDS_TREE_EXTRAS"); return e ? atoi(e) : 7; }();   // bit 0 mat, 1 emis, 2 geom
+            size_t used = fixed;
+            if ((extras & 1) && used + (size_t)n_prims * 16 <= LDS_LIMIT) { lt_mat = (size_t)n_prims * 16; used += lt_mat; }
+            if ((extras & 2) && used + (size_t)n_prims * 4 <= LDS_LIMIT) { lt_emis = (size_t)n_prims * 4; used += lt_emis; }
+            if ((extras & 4) && sc->n_sph && used + (size_t)sc->n_sph * 16 <= LDS_LIMIT) { lt_geom = (size_t)sc->n_sph * 16; used += lt_geom; }
+        }
+    }
     const bool streamed = !traverse && sc->n_sph_pad > RESIDENT_MAX;
     p.chunk = traverse ? 0 : (streamed ? STREAM_CHUNK : sc->n_sph_pad);
     p.n_chunks = p.chunk ? (sc->n_sph_pad + p.chunk - 1) / p.chunk : 0;
@@ -207,7 +225,10 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     // from the kernel's registers (exact nodes 6, quantised 5).  The exact-node kernel has 7 slots, fixed; the quantised
     // kernel's lists shrink from MAXL down to MINL slots to reach its target, and a quantised walk whose whole stack still
     // does not fit takes the capped-stack kernel.
-    const uint32_t stack_need = sc->bvh_depth + 1;
+    // stack slots per lane: up to bvh_depth pending right children (+ 1 spare); the LDS-tree kernel's branch-free step
+    // adds the DONE sentinel in slot 0 and needs the free slot its unconditional stores land in
+    const uint32_t stack_capped = sc->bvh_depth + 1;
+    const uint32_t stack_need = sc->bvh_depth + (ltree ? 2u : 1u);
     uint32_t maxl = qnodes ? (uint32_t)rtk::MAXL : (uint32_t)rtk::MAXL_EXACT, stack_lds = stack_need;
     bool capped = false;
     if (traverse && qnodes) {
@@ -218,8 +239,8 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
             maxl = (uint32_t)std::min<size_t>((size_t)rtk::MAXL, (per_wg - fixed) / slot);
         } else {
             static const uint32_t cap = [] { const char* e = getenv("RT_STACK_LDS"); return e && atoi(e) > 0 ? (uint32_t)atoi(e) : STACK_LDS_MAX; }();
-            capped = stack_need > cap;
-            stack_lds = std::min(stack_need, cap);
+            capped = stack_capped > cap;
+            stack_lds = capped ? cap : stack_need;
         }
     }
     p.maxl = maxl;
@@ -233,6 +254,24 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     p.lds_stack_off = (uint32_t)(geom_bytes + cand_bytes + path_bytes + rr_bytes);
     size_t stack_bytes = traverse ? (size_t)stack_lds * rtk::BLOCK * sizeof(uint32_t) : 0;
     size_t lds = geom_bytes + cand_bytes + path_bytes + rr_bytes + stack_bytes;
+    p.n_internal = sc->n_internal;
+    p.lds_node_off = 0;
+    p.lds_mat_off = p.lds_emis_off = p.lds_geom_off = 0xffffffffu;
+    const int bs = ltree ? rtk::LTREE_BLOCK : rtk::BLOCK;
+    if (ltree) {
+        // [nodes][mat][geom][emis][leaf lists u16][path u16][stack u16]
+        size_t off = ((size_t)sc->n_internal + 1) * 64;
+        if (lt_mat) { p.lds_mat_off = (uint32_t)off; off += lt_mat; }
+        if (lt_geom) { p.lds_geom_off = (uint32_t)off; off += lt_geom; }
+        if (lt_emis) { p.lds_emis_off = (uint32_t)off; off += (lt_emis + 15) & ~(size_t)15; }
+        p.lds_cand_off = (uint32_t)off;
+        off += (size_t)rtk::MAXL_LTREE * bs * sizeof(uint16_t);
+        p.lds_path_off = (uint32_t)off;
+        off += (size_t)p.depth * bs * sizeof(uint16_t);
+        p.lds_stack_off = (uint32_t)off;
+        off += (size_t)stack_need * bs * sizeof(uint16_t);
+        lds = off;
+    }
     if (lds > LDS_LIMIT) return fail(RT_ERR_LIMIT, "LDS budget exceeded (scene chunk + path stack)");
     fill_camera(rq, p);
     p.t_min = rq->t_min;
@@ -255,6 +294,7 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
         p.q_rstep[i] = 1.0f / sc->grid.step[i];
     }
     p.root_ref = sc->root_ref;
+    if (ltree && (p.root_ref & rtk::LEAF_BIT)) p.root_ref = 0x8000u | (p.root_ref & 0x7fffu);
     {
         // refill threshold: long walks (large scenes) want finished lanes replaced sooner, short walks amortise the
         // per-round shading / ray-generation code over more finished lanes (tools/variants_q.sh sweeps)
@@ -287,21 +327,22 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
 
     // persistent grid: as many workgroups as the chip holds at this LDS/VGPR budget
     int per_cu = 0;
-    const rtk::KernelFn kern = traverse ? rtk::kernel_traverse(qnodes ? (capped ? 2 : 1) : 0) : rtk::kernel_linear(streamed, expanded);
-    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, rtk::BLOCK, lds));
+    const rtk::KernelFn kern = traverse ? rtk::kernel_traverse(ltree ? 3 : qnodes ? (capped ? 2 : 1) : 0) : rtk::kernel_linear(streamed, expanded);
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, bs, lds));
     if (per_cu < 1) per_cu = 1;
     static const bool verbose = getenv("RT_VERBOSE") != nullptr;
     if (verbose)
         fprintf(stderr, "[rt] engine %d%s  lds %zu B  workgroups/CU %d  leaf slots %u  bvh depth %u  leaf density %.3f  prims %u\n",
-                traverse ? (qnodes ? 3 : 2) : (streamed ? 1 : 0), capped ? " (capped stack)" : "", lds, per_cu, maxl,
+                traverse ? (ltree ? 4 : qnodes ? 3 : 2) : (streamed ? 1 : 0), capped ? " (capped stack)" : "", lds, per_cu, maxl,
                 sc->bvh_depth, sc->leaf_density, n_prims);
     uint32_t blocks = (uint32_t)sc->ctx->n_cu * (uint32_t)per_cu;
-    const uint32_t useful = (p.n_tiles + 3) / 4;                 // a wave needs at least one tile
+    const uint32_t waves_per_wg = (uint32_t)bs / 64u;
+    const uint32_t useful = (p.n_tiles + waves_per_wg - 1) / waves_per_wg;   // a wave needs at least one tile
     if (blocks > useful) blocks = useful ? useful : 1;
-    p.ovf_stride = blocks * (uint32_t)rtk::BLOCK;
+    p.ovf_stride = blocks * (uint32_t)bs;
     p.stack_ovf = nullptr;
-    if (traverse && stack_need > stack_lds) {
-        const size_t words = (size_t)(stack_need - stack_lds) * p.ovf_stride;
+    if (traverse && capped) {
+        const size_t words = (size_t)(stack_capped - stack_lds) * p.ovf_stride;
         if (words > sc->stack_ovf_words) {
             if (sc->d_stack_ovf) {
                 HIPCHK(hipStreamSynchronize(stream));              // launches in flight may still use the old area
@@ -315,13 +356,13 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
         }
         p.stack_ovf = sc->d_stack_ovf;
     }
-    dim3 grid(blocks), block(rtk::BLOCK);
+    dim3 grid(blocks), block(bs);
     EvPair ev;
     int rc = get_events(sc, ev);
     if (rc) return rc;
     HIPCHK(hipMemsetAsync(p.queue, 0, sizeof(unsigned long long), stream));
     HIPCHK(hipEventRecord(ev.a, stream));
-    sc->last_engine = traverse ? (qnodes ? 3u : 2u) : (streamed ? 1u : 0u);
+    sc->last_engine = traverse ? (ltree ? 4u : qnodes ? 3u : 2u) : (streamed ? 1u : 0u);
     sc->last_form = expanded ? 1u : 0u;
     hipLaunchKernelGGL(kern, grid, block, lds, stream, p);
     HIPCHK(hipGetLastError());
@@ -447,7 +488,7 @@ static int ensure_ctx(DeviceCtx* c) {
         for (int expanded = 0; expanded < 2; expanded++)
             HIPCHK(hipFuncSetAttribute((const void*)rtk::kernel_linear(streamed != 0, expanded != 0),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
-    for (int variant = 0; variant < 3; variant++)
+    for (int variant = 0; variant < 4; variant++)
         HIPCHK(hipFuncSetAttribute((const void*)rtk::kernel_traverse(variant),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
     hipStream_t st = nullptr, cs = nullptr;
@@ -582,6 +623,7 @@ RT_API int rt_scene_create(int device, const rt_sphere* sp, uint32_t ns, const r
     if (bvh.leaf_of.empty()) bvh.leaf_of.push_back(0);
     sc->root_ref = bvh.root_ref;
     sc->bvh_depth = bvh.depth;
+    sc->n_internal = (uint32_t)bvh.trav.size();
     if (bvh.trav.empty()) bvh.trav.push_back(rtbvh::TravNode{});
     sc->grid = bvh.grid;
     if (bvh.travq.empty()) bvh.travq.push_back(rtbvh::QNode{});

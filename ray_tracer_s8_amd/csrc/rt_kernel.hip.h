@@ -42,6 +42,9 @@ constexpr int BLOCK = 256;       // 4 waves
 #ifndef RT_MINWAVES_TRAV
 #define RT_MINWAVES_TRAV 6       // exact-node kernel: 80 VGPRs, 2 spill slots outside the loops; c3 +1 %, c4 +2 % over 5
 #endif
+#ifndef RT_MINWAVES_LTREE       // LDS-resident tree: one workgroup of 16 waves per CU = 4 per SIMD, 128 VGPRs
+#define RT_MINWAVES_LTREE 4
+#endif
 #ifndef RT_MINWAVES_QTRAV       // quantised-node kernels: the bound is 4, the 90-92 VGPRs they take allow 5 waves/SIMD
 #define RT_MINWAVES_QTRAV 4
 #endif
@@ -65,6 +68,7 @@ constexpr int TRAV_STACK = 64;   // traversal stack entries per lane (host falls
 constexpr int MAXL = RT_MAXL;    // leaf-candidate slots per lane in traversal mode (flushed when full)
 constexpr int MINL = RT_MINL;
 constexpr int MAXL_EXACT = 7;     // exact-node kernel: fixed (see the kernel)
+constexpr int MAXL_LTREE = 12;    // LDS-tree kernel (16-bit entries): a block of RT_STEPS_PER_CHECK appends always fits
 constexpr uint32_t LEAF_BIT = 0x80000000u;
 
 struct StripDesc {
@@ -114,6 +118,9 @@ struct KParams {
     uint32_t ovf_stride;         //   threads in the grid (stride of the overflow area)
     uint32_t* stack_ovf;         //   [entries beyond stack_lds][ovf_stride]
     uint32_t refill_eighths;     // traversal: finished lanes are refilled once <= this many eighths of the live lanes still walk
+    uint32_t n_internal;         // internal nodes of the tree (= TravNode count)
+    uint32_t lds_node_off;       // LDS-resident tree (ISECT 5): byte offsets of the staged nodes ...
+    uint32_t lds_mat_off, lds_emis_off, lds_geom_off;   //   ... materials / emission / (cx,cy,cz,rr); 0xffffffff = stays in HBM
     const float4* bvh_nodes;     // [2*n_nodes]: (lo.xyz, parent as bits) (hi.xyz, -) — rt_bvh.h FlatNode
     const uint32_t* leaf_of;     // [n_sph+n_tri] primitive -> leaf node index (= DFS rank)
     unsigned long long* counters;// [0] segments [1] candidates [2] fallbacks
@@ -431,6 +438,18 @@ __device__ __forceinline__ uint8_t f32_as_u8(float v) {
 #define WCOUNT(slot) do { } while (0)
 #define LCOUNT(slot) do { } while (0)
 #endif
+// Phase clock for tuning (compile with -DRT_PROFILE_TIME; tools/phase_time.py): wave cycles (s_memtime) between
+// consecutive stamps are charged to the phase named by the stamp that ends the interval; one total per phase in
+// the spare queue slots [8192 + 160 ..].
+#ifdef RT_PROFILE_TIME
+#define TDECL unsigned long long _tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long _tlast = __builtin_amdgcn_s_memtime()
+#define TSTAMP(ph) do { const unsigned long long _n = __builtin_amdgcn_s_memtime(); _tacc[ph] += _n - _tlast; _tlast = _n; } while (0)
+#define TFLUSH do { if ((threadIdx.x & 63) == 0) for (int _i = 0; _i < 8; _i++) atomicAdd(&p.counters[4 + 8192 + 160 + _i], _tacc[_i]); } while (0)
+#else
+#define TDECL do { } while (0)
+#define TSTAMP(ph) do { } while (0)
+#define TFLUSH do { } while (0)
+#endif
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
@@ -447,15 +466,23 @@ __device__ __forceinline__ const T& at32(const T* __restrict__ base, uint32_t i)
 // through LDS in chunks; 2 = per-lane traversal of the reference BVH (exact 64-byte nodes); 3 = the same walk over
 // 32-byte nodes whose boxes are rounded outwards onto a 16-bit grid, every reached leaf being validated with the
 // reference's exact own-leaf AABB test.
-template <int ISECT, bool EXPANDED>
-__global__ __launch_bounds__(BLOCK, ISECT >= 3 ? RT_MINWAVES_QTRAV : ISECT == 2 ? RT_MINWAVES_TRAV : RT_MINWAVES) void rt_tile_kernel(const KParams p) {
+template <int ISECT, bool EXPANDED, int BS = BLOCK>
+__global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 3 ? RT_MINWAVES_QTRAV : ISECT == 2 ? RT_MINWAVES_TRAV : RT_MINWAVES) void rt_tile_kernel(const KParams p) {
+    constexpr int BLOCK = BS;                        // threads per workgroup = stride of the per-lane LDS arrays
     constexpr bool STREAMED = (ISECT == 1);
     constexpr bool TRAVERSE = (ISECT >= 2);
     constexpr bool QNODES = (ISECT == 3 || ISECT == 4);   // traversal over 32-byte conservatively quantised nodes
     constexpr bool CAPPED = (ISECT == 4);            // ... whose stack keeps p.stack_lds entries in LDS, deeper ones in HBM
+    // ISECT 5: the exact-node walk with the WHOLE tree (and the materials) resident in LDS, one 1024-thread workgroup
+    // per CU; references, stack and leaf lists are 16-bit
+    constexpr bool LTREE = (ISECT == 5);
+    constexpr uint32_t LB = LTREE ? 0x8000u : LEAF_BIT;   // leaf flag of a node reference
+    // the branch-free node step (see there) pays where a step is bound by the wave's instruction stream = nodes in LDS;
+    // the L2-gather engines are bound by the gathers and keep the step that skips them at leaves (c3 -14 %, c5 -11 %)
+    constexpr bool BFSTEP = LTREE;
     // leaf-list slots per lane: the exact-node kernel's are fixed (7 KiB lets six of its workgroups share a CU's LDS on
     // c3-class trees; a run-time count cost it 1 %), the quantised kernels' are chosen by the host's LDS plan
-    const uint32_t ML = QNODES ? p.maxl : (uint32_t)MAXL_EXACT;
+    const uint32_t ML = QNODES ? p.maxl : (uint32_t)MAXL_EXACT;   // (LTREE: MAXL_LTREE, see its step)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     float4* lgeom = reinterpret_cast<float4*>(lds_raw);          // pair layout, see KParams::geom_pk / geom_px
     const float* lgeomf = reinterpret_cast<const float*>(lds_raw);
@@ -474,6 +501,52 @@ __global__ __launch_bounds__(BLOCK, ISECT >= 3 ? RT_MINWAVES_QTRAV : ISECT == 2 
             for (uint32_t i = tid; i < p.n_sph_pad; i += BLOCK) lrr[i] = p.geom[i].w;
         __syncthreads();
     }
+
+    if (LTREE) {
+        // stage the whole tree once per workgroup; child references become 16-bit (leaf flag 0x8000)
+        float4* ln = reinterpret_cast<float4*>(lds_raw + p.lds_node_off);
+        for (uint32_t i = tid; i < 4u * p.n_internal; i += BLOCK) {
+            float4 v = p.trav[i];
+            if ((i & 2u) == 0) {                                   // (l_lo, left) and (l_hi, right)
+                uint32_t r = __float_as_uint(v.w);
+                if (r & LEAF_BIT) r = 0x8000u | (r & 0x7fffu);
+                v.w = __uint_as_float(r);
+            }
+            ln[i] = v;
+        }
+        if (tid < 4) {                                             // node DONE: NaN boxes, entered by no ray
+            const float qn = __builtin_nanf("");
+            ln[4u * p.n_internal + tid] = make_float4(qn, qn, qn, __uint_as_float(p.n_internal));
+        }
+        const uint32_t np = p.n_sph + p.n_tri;
+        if (p.lds_mat_off != 0xffffffffu) {
+            float4* lm = reinterpret_cast<float4*>(lds_raw + p.lds_mat_off);
+            for (uint32_t i = tid; i < np; i += BLOCK) lm[i] = p.mat[i];
+        }
+        if (p.lds_emis_off != 0xffffffffu) {
+            float* le = reinterpret_cast<float*>(lds_raw + p.lds_emis_off);
+            for (uint32_t i = tid; i < np; i += BLOCK) le[i] = p.emis[i];
+        }
+        if (p.lds_geom_off != 0xffffffffu) {
+            float4* lg = reinterpret_cast<float4*>(lds_raw + p.lds_geom_off);
+            for (uint32_t i = tid; i < p.n_sph; i += BLOCK) lg[i] = p.geom[i];
+        }
+        __syncthreads();
+    }
+    const float4* const lnodes = reinterpret_cast<const float4*>(lds_raw + p.lds_node_off);
+    // material / geometry fetch: LDS copy when the launch staged one, else HBM (L2)
+    auto mat_at = [&](uint32_t i) -> float4 {
+        if (LTREE && p.lds_mat_off != 0xffffffffu) return reinterpret_cast<const float4*>(lds_raw + p.lds_mat_off)[i];
+        return at32(p.mat, i);
+    };
+    auto emis_at = [&](uint32_t i) -> float {
+        if (LTREE && p.lds_emis_off != 0xffffffffu) return reinterpret_cast<const float*>(lds_raw + p.lds_emis_off)[i];
+        return at32(p.emis, i);
+    };
+    auto geom_at = [&](uint32_t i) -> float4 {
+        if (LTREE && p.lds_geom_off != 0xffffffffu) return reinterpret_cast<const float4*>(lds_raw + p.lds_geom_off)[i];
+        return at32(p.geom, i);
+    };
 
     const V3 corg = mk(p.org[0], p.org[1], p.org[2]);
     const V3 llc = mk(p.llc[0], p.llc[1], p.llc[2]);
@@ -517,6 +590,10 @@ __global__ __launch_bounds__(BLOCK, ISECT >= 3 ? RT_MINWAVES_QTRAV : ISECT == 2 
     bool qfin = false;                       // QNODES: this lane may use the quantised boxes
     uint32_t* lc32 = reinterpret_cast<uint32_t*>(lds_raw + p.lds_cand_off);     // TRAVERSE: leaf candidates (u32)
     uint32_t* lstack = reinterpret_cast<uint32_t*>(lds_raw + p.lds_stack_off);   // TRAVERSE: per-lane stack
+    uint16_t* lc16 = reinterpret_cast<uint16_t*>(lds_raw + p.lds_cand_off);     // LTREE: both 16-bit
+    uint16_t* lstack16 = reinterpret_cast<uint16_t*>(lds_raw + p.lds_stack_off);
+
+    if (BFSTEP) lstack16[tid] = (uint16_t)p.n_internal;  // stack slot 0: popping an empty stack yields DONE
 
     auto drain_counters = [&]() {
         const unsigned long long ws = wave_sum(n_seg), wc = wave_sum(n_cand), wf = wave_sum(n_fall);
@@ -527,8 +604,10 @@ __global__ __launch_bounds__(BLOCK, ISECT >= 3 ? RT_MINWAVES_QTRAV : ISECT == 2 
         }
         n_seg = n_cand = n_fall = 0;
     };
+    TDECL;
     for (;;) {
         WCOUNT(0);
+        TSTAMP(5);
         if (TRAVERSE && __ballot(((n_seg | n_cand | n_fall) & 0x80000000u) != 0)) drain_counters();
         // ================= pixel acquisition: lanes pull pixels of the wave's current tile
         {
@@ -588,6 +667,7 @@ __global__ __launch_bounds__(BLOCK, ISECT >= 3 ? RT_MINWAVES_QTRAV : ISECT == 2 
             }
         }
         const bool active = have_pixel;
+        TSTAMP(0);
         if (active && need_ray) {
             // ---- next ray of the lane: the camera ray of a new sample (Camera::get_ray, camera.rs:109-129) or the
             // scattered ray of a bounce (main.rs:119-127).  Both start with a rejection-sampled pair of
@@ -632,6 +712,7 @@ __global__ __launch_bounds__(BLOCK, ISECT >= 3 ? RT_MINWAVES_QTRAV : ISECT == 2 
             need_ray = false;
             bounce = false;
         }
+        TSTAMP(1);
         if (STREAMED) {
             if (!__syncthreads_or(active ? 1 : 0)) break;
         } else {
@@ -660,7 +741,7 @@ __global__ __launch_bounds__(BLOCK, ISECT >= 3 ? RT_MINWAVES_QTRAV : ISECT == 2 
             }
             if (TRAVERSE) {
                 t_ref = p.root_ref;
-                t_sp = 0;
+                t_sp = BFSTEP ? 1u : 0u;                     // slot 0 of the branch-free step's stack holds the DONE sentinel
                 t_cnt = 0;
                 in_trav = (p.n_sph + p.n_tri) > 0;
             }
@@ -673,10 +754,11 @@ __global__ __launch_bounds__(BLOCK, ISECT >= 3 ? RT_MINWAVES_QTRAV : ISECT == 2 
             // Steps run until at most half of the wave's live lanes are still walking; the finished lanes are then
             // shaded / refilled while the stragglers keep their stack (LDS) and resume in the next round.
             auto flush = [&]() {
+                if (BFSTEP) n_cand += t_cnt;                     // (the other steps count at the append)
 #pragma clang loop unroll(disable)
                 for (uint32_t i = 0; i < t_cnt; i++) {
                     LCOUNT(6);
-                    const uint32_t prim = lc32[i * BLOCK + tid];
+                    const uint32_t prim = LTREE ? (uint32_t)lc16[i * BLOCK + tid] & 0x7fffu : lc32[i * BLOCK + tid];
                     float t;
                     // The quantised walk only over-approximates BVH::traverse, so a leaf it delivers counts iff
                     // the reference would have reached it = its own exact box passes (leaf-box lemma, bvh_reaches;
@@ -684,7 +766,7 @@ __global__ __launch_bounds__(BLOCK, ISECT >= 3 ? RT_MINWAVES_QTRAV : ISECT == 2 
                     // lazily: only to a hit that would replace the running closest one.  (A lane without a finite
                     // inverse direction walked the exact nodes: nothing to validate.)
                     if (prim < p.n_sph) {
-                        const float4 g = at32(p.geom, prim);
+                        const float4 g = geom_at(prim);
                         if (exact_sphere(o, 2.0f * d, mk(g.x, g.y, g.z), g.w, p.t_min, p.t_max, t)) {   // (2f32 * ray.direction), sphere.rs:44
                             if (QNODES)
                                 consider_if(h, (int)prim, o, d, t, [&]() {
@@ -712,15 +794,79 @@ __global__ __launch_bounds__(BLOCK, ISECT >= 3 ? RT_MINWAVES_QTRAV : ISECT == 2 
             // kernel (large scenes, deep trees) keeps p.stack_lds entries there and the rare deeper ones in HBM, so
             // that the tree's depth does not take the CU's LDS away from its occupancy.
             auto push = [&](uint32_t v) {
-                if (!CAPPED || t_sp < p.stack_lds) lstack[t_sp * BLOCK + tid] = v;
+                if (LTREE) lstack16[t_sp * BLOCK + tid] = (uint16_t)v;
+                else if (!CAPPED || t_sp < p.stack_lds) lstack[t_sp * BLOCK + tid] = v;
                 else p.stack_ovf[(size_t)(t_sp - p.stack_lds) * p.ovf_stride + (blockIdx.x * BLOCK + tid)] = v;
                 t_sp++;
             };
             auto pop = [&]() -> uint32_t {
                 --t_sp;
+                if (LTREE) return (uint32_t)lstack16[t_sp * BLOCK + tid];
                 if (!CAPPED || t_sp < p.stack_lds) return lstack[t_sp * BLOCK + tid];
                 return p.stack_ovf[(size_t)(t_sp - p.stack_lds) * p.ovf_stride + (blockIdx.x * BLOCK + tid)];
             };
+            if constexpr (BFSTEP) {
+            // ---- Branch-free node step of the LDS-resident tree.  With the nodes a few dozen cycles
+            // away a wave's time per step is the length of its serial instruction stream, scalar exec-mask bookkeeping
+            // and branches included, and the earlier step (a dozen exec regions: leaf / internal, push, pop, list
+            // append, emptiness and fullness tests) spent more instructions on control than on the two slab tests.
+            // Here every lane of the block runs the same straight line and the state advances through selects:
+            //   * node DONE (= n_internal) is a dummy whose boxes are NaN: no ray enters it.  Stack slot 0 holds DONE
+            //     for good and t_sp >= 1, so popping the empty stack yields DONE, and DONE pops DONE: a finished lane
+            //     idles there until the block ends — no emptiness test, no per-lane exit;
+            //   * a lane at a leaf gathers DONE too, so its two slab results are false and it pops;
+            //   * the right child is stored to stack[t_sp], the next free slot, pushed or not (t_sp += both);
+            //   * a leaf is stored to list[t_cnt], anything else to that same free stack slot (overwritten next);
+            //   * the leaf list has room for a whole block of appends (checked between blocks): no fullness test.
+            // The crate's literal slab test (a +-0 direction component, or RT_FLAG_FULL_CHAIN) is chosen per BLOCK of
+            // steps for the whole wave: it is the reference's own test, valid for every lane.
+            const uint32_t DONE = p.n_internal;
+            constexpr int STEPS = RT_STEPS_PER_CHECK;
+            static_assert(MAXL_LTREE > STEPS, "the leaf list must take a block of appends");
+            auto step = [&](auto slow_tag) {
+                constexpr bool SLOW = decltype(slow_tag)::value;
+                const bool is_leaf = t_ref > 0x7fffu;
+                const uint32_t ni = is_leaf ? DONE : t_ref;
+                const uint32_t top = (uint32_t)lstack16[(t_sp - 1u) * BLOCK + tid];
+                WCOUNT(5);
+                LCOUNT(5);
+                uint16_t* const dst = is_leaf ? &lc16[t_cnt * BLOCK + tid] : &lstack16[t_sp * BLOCK + tid];
+                *dst = (uint16_t)t_ref;                          // (the flush masks the leaf flag off)
+                const float4* __restrict__ nd = lnodes + (ni << 2);
+                const float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
+                bool hl, hr;
+                if (SLOW) {                                      // the crate's literal form (ray.rs:174-194)
+                    hl = intersects_aabb(o, aux, n0, n1);
+                    hr = intersects_aabb(o, aux, n2, n3);
+                } else {
+                    hl = intersects_aabb_finite(o, aux, n0, n1);
+                    hr = intersects_aabb_finite(o, aux, n2, n3);
+                }
+                const uint32_t cl = __float_as_uint(n0.w), cr = __float_as_uint(n1.w);
+                lstack16[t_sp * BLOCK + tid] = (uint16_t)cr;     // right subtree after the whole left subtree
+                const bool any = hl || hr;
+                t_ref = any ? (hl ? cl : cr) : top;
+                t_sp = max(t_sp + ((hl && hr) ? 1u : 0u) - (any ? 0u : 1u), 1u);
+                t_cnt += is_leaf ? 1u : 0u;
+            };
+            for (;;) {
+                const uint32_t walking = (uint32_t)__builtin_popcountll(__ballot(in_trav));
+                const uint32_t live = (uint32_t)__builtin_popcountll(__ballot(true));
+                if (walking == 0 || (walking * 8 <= live * p.refill_eighths && walking < live)) break;
+                if (in_trav && t_cnt > (uint32_t)(MAXL_LTREE - STEPS)) flush();   // room for a block of appends
+                const bool slow = __ballot(in_trav && !aux.finite) != 0;         // wave-uniform
+                if (in_trav) {
+                    if (slow) {
+#pragma unroll
+                        for (int rep = 0; rep < STEPS; rep++) step(std::true_type{});
+                    } else {
+#pragma unroll
+                        for (int rep = 0; rep < STEPS; rep++) step(std::false_type{});
+                    }
+                    in_trav = t_ref != DONE;
+                }
+            }
+            } else {
             for (;;) {
                 const uint32_t walking = (uint32_t)__builtin_popcountll(__ballot(in_trav));
                 const uint32_t live = (uint32_t)__builtin_popcountll(__ballot(true));
@@ -739,13 +885,14 @@ __global__ __launch_bounds__(BLOCK, ISECT >= 3 ? RT_MINWAVES_QTRAV : ISECT == 2 
                 if (in_trav) {
                     WCOUNT(5);
                     LCOUNT(5);
-                    if (t_ref & LEAF_BIT) {
+                    if (t_ref & LB) {
 #ifdef RT_FLUSH_INLINE
                         if (t_cnt == ML) flush();
 #else
                         if (t_cnt == ML) continue;
 #endif
-                        lc32[t_cnt * BLOCK + tid] = t_ref & ~LEAF_BIT;
+                        if (LTREE) lc16[t_cnt * BLOCK + tid] = (uint16_t)(t_ref & 0x7fffu);
+                        else lc32[t_cnt * BLOCK + tid] = t_ref & ~LEAF_BIT;
                         t_cnt++;
                         n_cand++;
                         if (t_sp == 0) {
@@ -818,7 +965,10 @@ __global__ __launch_bounds__(BLOCK, ISECT >= 3 ? RT_MINWAVES_QTRAV : ISECT == 2 
                     }
                 }
             }
+            }
+            TSTAMP(2);
             if (active && !in_trav) flush();                 // exact root tests of the finished lanes, together
+            TSTAMP(3);
         } else {
             bool seg_active = active;
             bool inline_chain = false;
@@ -985,8 +1135,8 @@ __global__ __launch_bounds__(BLOCK, ISECT >= 3 ? RT_MINWAVES_QTRAV : ISECT == 2 
             if (h.idx >= 0) {
                 WCOUNT(8);
                 LCOUNT(8);
-                const float em = at32(p.emis, (uint32_t)h.idx);
-                const float4 m = at32(p.mat, (uint32_t)h.idx);
+                const float em = emis_at((uint32_t)h.idx);
+                const float4 m = mat_at((uint32_t)h.idx);
                 if (em > 0.0f) {                              // main.rs:116-117
                     term_r = m.x * em;
                     term_g = m.y * em;
@@ -995,7 +1145,7 @@ __global__ __launch_bounds__(BLOCK, ISECT >= 3 ? RT_MINWAVES_QTRAV : ISECT == 2 
                 } else {
                     V3 n;
                     if ((uint32_t)h.idx < p.n_sph) {
-                        float4 g = at32(p.geom, (uint32_t)h.idx);
+                        float4 g = geom_at((uint32_t)h.idx);
                         n = normalize_or_zero(h.p - mk(g.x, g.y, g.z));             // sphere.rs:49-51
                     } else {
                         const float* tv = p.tri + 9 * (size_t)(h.idx - p.n_sph);
@@ -1050,7 +1200,7 @@ __global__ __launch_bounds__(BLOCK, ISECT >= 3 ? RT_MINWAVES_QTRAV : ISECT == 2 
                     LCOUNT(11);
                     uint32_t idx = p.path32 ? reinterpret_cast<uint32_t*>(lpath)[i * BLOCK + tid]
                                             : (uint32_t) reinterpret_cast<uint16_t*>(lpath)[i * BLOCK + tid];
-                    float4 m = at32(p.mat, (uint32_t)idx);
+                    float4 m = mat_at((uint32_t)idx);
                     term_r = m.x * term_r;
                     term_g = m.y * term_g;
                     term_b = m.z * term_b;
@@ -1082,14 +1232,18 @@ __global__ __launch_bounds__(BLOCK, ISECT >= 3 ? RT_MINWAVES_QTRAV : ISECT == 2 
                 }
             }
         }
+        TSTAMP(4);
     }
 
     drain_counters();
+    TFLUSH;
 }
 
 // The kernels are instantiated in rt_kernels_lin.hip / rt_kernels_trav.hip; the host side (rt_api.hip) gets them here.
 using KernelFn = void (*)(const KParams);
 KernelFn kernel_linear(bool streamed, bool expanded);
-KernelFn kernel_traverse(int variant);   // 0: exact nodes, 1: quantised nodes, 2: quantised nodes with the capped LDS stack
+KernelFn kernel_traverse(int variant);   // 0: exact nodes, 1: quantised nodes, 2: quantised nodes with the capped LDS stack,
+                                         // 3: exact nodes, whole tree resident in LDS (1024-thread workgroups)
+constexpr int LTREE_BLOCK = 1024;
 
 }  // namespace rtk

@@ -6,6 +6,7 @@
 
 namespace rtk {
 KernelFn kernel_traverse(int variant) {
+    if (variant == 3) return rt_tile_kernel<5, false, LTREE_BLOCK>;
     return variant == 2 ? rt_tile_kernel<4, false> : variant == 1 ? rt_tile_kernel<3, false> : rt_tile_kernel<2, false>;
 }
 }  // namespace rtk

@@ -65,10 +65,14 @@ def test_c3_full_4k_bit_exact_and_filter_is_conservative(ndev, oracle):
     # property: broad phase off (exact root computation against every sphere) == broad phase on
     rgb_x, _, st_x = _frame_gpu(sph, rq, flags=rt.RT_FLAG_EXACT_SCAN)
     assert np.array_equal(rgb_x, rgb) and st_x.ray_segments == st.ray_segments
-    # default engine here = traversal over exact nodes; the quantised nodes give the same frame
+    # default engine here = traversal over exact nodes resident in LDS; the same nodes gathered from L2 and the
+    # quantised nodes give the same frame
     rgb_e, _, st_e = _frame_gpu(sph, rq, flags=128)
-    assert st.engine == 2 and st_e.engine == 3
+    assert st.engine == 4 and st_e.engine == 3
     assert np.array_equal(rgb_e, rgb) and st_e.ray_segments == st.ray_segments
+    rgb_g, _, st_g = _frame_gpu(sph, rq, flags=256)          # RT_FLAG_NO_LDS_TREE
+    assert st_g.engine == 2
+    assert np.array_equal(rgb_g, rgb) and st_g.ray_segments == st.ray_segments
     # the two broad-phase forms of the linear engine (8-op expanded, 11-op oc) agree at full size
     rgb_o, _, st_o = _frame_gpu(sph, rq, flags=4 | 32)
     assert np.array_equal(rgb_o, rgb) and st_o.ray_segments == st.ray_segments

@@ -13,7 +13,10 @@ from ray_tracer_s8_amd import _abi
 ENGINE_FLAGS = [0, _abi.RT_FLAG_LINEAR_SCAN, _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_QUANT_NODES,
                 _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_EXACT_NODES,
                 _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_FULL_CHAIN, _abi.RT_FLAG_LINEAR_SCAN | _abi.RT_FLAG_OC_BROAD_PHASE,
-                _abi.RT_FLAG_NO_BVH_CULL, _abi.RT_FLAG_EXACT_SCAN, _abi.RT_FLAG_LINEAR_SCAN | _abi.RT_FLAG_FULL_CHAIN]
+                _abi.RT_FLAG_NO_BVH_CULL, _abi.RT_FLAG_EXACT_SCAN, _abi.RT_FLAG_LINEAR_SCAN | _abi.RT_FLAG_FULL_CHAIN,
+                # small trees walk an LDS-resident copy by default; keep the L2-gather walks of the same nodes covered
+                _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_EXACT_NODES | _abi.RT_FLAG_NO_LDS_TREE,
+                _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_FULL_CHAIN | _abi.RT_FLAG_NO_LDS_TREE]
 
 
 @pytest.fixture(scope="module")
@@ -55,7 +58,7 @@ def _random_case(i):
     return sph, tri, rq, flags
 
 
-N_CASES = int(os.environ.get("RT_FUZZ_CASES", "56"))      # RT_FUZZ_CASES=1000 for a long soak
+N_CASES = int(os.environ.get("RT_FUZZ_CASES", "66"))      # RT_FUZZ_CASES=1000 for a long soak
 
 
 @pytest.mark.parametrize("i", range(N_CASES))

@@ -192,10 +192,14 @@ def test_bvh_traversal_engine(ndev, oracle, scene):
         sph = scenes.rand65536(n=9000)
         rq = _abi.default_request(width=128, height=80, divisions=1, spp=2, max_bounces=5, seed=99)
     a = _compare(oracle, rq, sph, tri, flags=_abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_QUANT_NODES)
-    c = _compare(oracle, rq, sph, tri, flags=_abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_EXACT_NODES)
+    c = _compare(oracle, rq, sph, tri, flags=_abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_EXACT_NODES | _abi.RT_FLAG_NO_LDS_TREE)
     b = _compare(oracle, rq, sph, tri, flags=_abi.RT_FLAG_LINEAR_SCAN)
-    assert a.ray_segments == b.ray_segments == c.ray_segments
+    # the exact nodes walked from an LDS-resident copy (the default for trees that fit; a single-leaf tree has no nodes)
+    e = _compare(oracle, rq, sph, tri, flags=_abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_EXACT_NODES)
+    assert a.ray_segments == b.ray_segments == c.ray_segments == e.ray_segments
     assert c.engine == 2 and b.engine in (0, 1)
+    assert e.engine == (4 if scene in ("c2", "c3", "mesh") else 2)
+    assert e.broad_candidates == c.broad_candidates                    # same tree, same leaves reached
     assert a.broad_candidates >= c.broad_candidates                    # rounded boxes can only admit more leaves
 
 
