@@ -33,6 +33,7 @@ sys.path.insert(0, str(ROOT))
 PEAK_FP32_VALU_TFLOPS = 157.3      # MI355X_MICROARCH.md: peak FP32 vector (FMA = 2 flop)
 PEAK_HBM_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FLOPS_PER_TEST = 20                # faithful ray-sphere test = 20 flop + 1 sqrt
+FLOPS_PER_NODE_STEP = 48           # two child-box slab tests: 2 x (6 sub + 6 mul + 12 min / max / compare)
 
 
 def parse_args():
@@ -47,6 +48,9 @@ def parse_args():
                     "tail; per-launch HIP-event times then include queueing and the roofline object is not comparable")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-buffer (PCIe-inclusive) pass: profiling runs "
                     "then see whole-frame launches only")
+    ap.add_argument("--no-linear", action="store_true", help="skip the linear-engine launches behind roofline_linear")
+    ap.add_argument("--strong", action="store_true", help="strong scaling, the controller's split (BASELINE c4 / c5): ONE "
+                    "frame, strip d goes to rank d mod N; value = the frame's ray segments / max-rank time")
     ap.add_argument("--cpu-scale", type=int, default=1, help="CPU baseline renders the frame at 1/scale resolution")
     ap.add_argument("--flags", type=int, default=0, help="rt_tile_request.flags (1 = exact scan)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -112,7 +116,8 @@ def main():
 
     import ray_tracer_s8_amd as rt
     from ray_tracer_s8_amd import scenes
-    from ray_tracer_s8_amd.dispatch import job_shards
+    from ray_tracer_s8_amd import _abi
+    from ray_tracer_s8_amd.dispatch import job_shards, strips_for_worker
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
@@ -130,8 +135,15 @@ def main():
     assert dev_index < n_dev
     sph, rq0 = scenes.config(args.workload)
     rq0.flags = args.flags
-    n_frames = world                                   # weak scaling: one frame of work per GPU
-    units = job_shards(n_frames, rq0.divisions, rank, world)
+    if args.strong:
+        # the controller's split of ONE frame (controller main.rs:47-75): strip d -> rank d mod N
+        n_frames = 1
+        if rq0.divisions % world:
+            raise SystemExit(f"--strong: {rq0.divisions} strips do not divide over {world} ranks")
+        units = [(0, d) for d in strips_for_worker(rq0.divisions, rank, world)]
+    else:
+        n_frames = world                               # weak scaling: one frame of work per GPU
+        units = job_shards(n_frames, rq0.divisions, rank, world)
     strip_bytes = (rq0.height // rq0.divisions) * rq0.width * 3
     out = torch.empty(len(units) * strip_bytes, dtype=torch.uint8, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream   # kernels and torch.cuda.synchronize share it
@@ -208,27 +220,85 @@ def main():
                 "mrays_per_s": float(st_h.ray_segments) / (th1 - th0) / 1e6,
                 "scene_h2d_bytes": int(36 * len(sph))}
 
+    # ---- work census for the roofline object (rank 0, outside the timed region): one more launch of the same
+    # frame through the kernel's counting twin (RT_FLAG_COUNT_STEPS: same image, also counts the BVH nodes visited).
+    # The render is deterministic in (scene, seed), so the counts are exactly those of every timed launch.
+    census = None
+    if rank == 0 and st.engine >= 2:
+        creqs = []
+        for r in reqs:
+            c = r.copy()
+            c.flags = r.flags | _abi.RT_FLAG_COUNT_STEPS
+            creqs.append(c)
+        scene.render_tiles_device(creqs, out_ptrs, strip_bytes, stream)
+        torch.cuda.synchronize()
+        sc_ = scene.collect()
+        census = {"segments": int(sc_.ray_segments), "node_steps": int(sc_.node_steps),
+                  "root_tests": int(sc_.broad_candidates), "launch_ms_counting_twin": sc_.kernel_ms}
+    # ---- the north-star-shaped kernel beside it: linear scan over the LDS-resident primitive list (flags 32), the engine
+    # that performs SURVEY 8(d)'s N exact-or-conservative sphere tests per segment.  Own launches, own HIP-event timing.
+    linear = None
+    if rank == 0 and world == 1 and st.engine >= 2 and len(sph) <= 2048 and not args.no_linear and not args.overlap:
+        lreqs = []
+        for r in reqs:
+            c = r.copy()
+            c.flags = _abi.RT_FLAG_LINEAR_SCAN
+            lreqs.append(c)
+        scene.render_tiles_device(lreqs, out_ptrs, strip_bytes, stream)     # warm-up
+        torch.cuda.synchronize()
+        scene.collect()
+        for _ in range(max(1, min(args.steps, 3))):
+            scene.render_tiles_device(lreqs, out_ptrs, strip_bytes, stream)
+        torch.cuda.synchronize()
+        sl = scene.collect()
+        l_launch_s = sl.kernel_ms / 1e3 / max(sl.n_launches, 1)
+        l_tflops = float(sl.ray_segments) / max(sl.n_launches, 1) * FLOPS_PER_TEST * len(sph) / l_launch_s / 1e12
+        linear = {"bound": "valu", "kernel": "rtk::rt_tile_kernel<0, expanded> (linear scan, scene resident in LDS)",
+                  "achieved": l_tflops, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
+                  "frac": l_tflops / PEAK_FP32_VALU_TFLOPS, "avg_launch_ms": l_launch_s * 1e3,
+                  "launches": int(sl.n_launches), "mrays_per_s": float(sl.ray_segments) / (sl.kernel_ms / 1e3) / 1e6,
+                  "work": f"ray segments/launch x {FLOPS_PER_TEST} flop x {len(sph)} spheres (SURVEY 8(d)): this engine tests "
+                          "every sphere against every segment"}
+        assert 0.0 < linear["frac"] <= 1.0, linear
+
     if rank == 0:
         n_sph = len(sph)
         launches = max(st.n_launches, 1)
         avg_launch_s = st.kernel_ms / 1e3 / launches
         segs_per_launch = float(st.ray_segments) / launches
-        achieved_tflops = segs_per_launch * FLOPS_PER_TEST * n_sph / avg_launch_s / 1e12
+        algorithmic_equiv_tflops = segs_per_launch * FLOPS_PER_TEST * n_sph / avg_launch_s / 1e12
+        if st.engine >= 2:
+            # executed work of the traversal engines: per internal node visited two child-box slab tests
+            # (2 x (6 sub + 6 mul + 12 min / max / compare) = 48 flop), per leaf reached one exact root test (20 flop + sqrt)
+            scale = segs_per_launch / max(census["segments"], 1)          # launches of the step = census launch (1.0)
+            flops_per_launch = (census["node_steps"] * FLOPS_PER_NODE_STEP + census["root_tests"] * FLOPS_PER_TEST) * scale
+            work = {"node_steps_per_segment": census["node_steps"] / max(census["segments"], 1),
+                    "root_tests_per_segment": census["root_tests"] / max(census["segments"], 1),
+                    "flops_per_node_step": FLOPS_PER_NODE_STEP, "flops_per_root_test": FLOPS_PER_TEST,
+                    "source": "counting twin of the timed kernel, one extra launch of the same frame in this run"}
+        else:
+            flops_per_launch = segs_per_launch * FLOPS_PER_TEST * n_sph
+            work = {"tests_per_segment": n_sph, "flops_per_test": FLOPS_PER_TEST,
+                    "source": "SURVEY 8(d): the linear engine tests every sphere against every segment"}
+        achieved_tflops = flops_per_launch / avg_launch_s / 1e12
         hbm_bytes_per_launch = strip_bytes * len(reqs) / max(len(batches), 1) + 36 * n_sph   # RGB8 out + scene in
-        traffic = None
-        tp = ROOT / "profiles" / "hbm_traffic.json"
-        if tp.exists():
+
+        def committed(name):
+            fp = ROOT / "profiles" / name
             try:
-                traffic = json.loads(tp.read_text()).get(args.workload, {}).get("bytes_per_launch")
+                d = json.loads(fp.read_text()).get(args.workload)
             except Exception:
-                traffic = None
-        issue = None
-        ip = ROOT / "profiles" / "valu_issue.json"
-        if ip.exists():
-            try:
-                issue = json.loads(ip.read_text()).get(args.workload)
-            except Exception:
-                issue = None
+                return None
+            if isinstance(d, dict):
+                d = dict(d)
+                d["source"] = f"committed profile profiles/{name} (rocprofv3 --pmc pass of this command, not measured in this run)"
+            return d
+        traffic_rec = committed("r02_hbm_traffic.json")
+        issue = committed("r02_valu_issue.json")
+        eng_names = ["linear scan, scene resident in LDS", "linear scan, scene streamed through LDS",
+                     "per-lane traversal of the reference BVH (exact nodes gathered from L2)",
+                     "per-lane traversal of the reference BVH (quantised nodes, exact leaf validation)",
+                     "per-lane traversal of the reference BVH (exact nodes resident in LDS)"]
         line = {
             "metric": "Mrays/sec @ 4K/8spp 1024-sphere" if args.workload == "c3" else f"Mrays/sec @ {args.workload}",
             "value": segs / elapsed / 1e6,
@@ -238,21 +308,19 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
                 "workload": f"{args.workload}: {n_sph} spheres, {rq0.width}x{rq0.height}, {rq0.spp} spp, "
-                            f"depth {rq0.max_bounces}, {rq0.divisions} strips/frame, {n_frames} frame(s) "
-                            f"sharded by strip over {world} GPU(s)",
+                            f"depth {rq0.max_bounces}, {rq0.divisions} strips/frame, "
+                            + (f"ONE frame, strip d -> rank d mod {world} (controller split)" if args.strong else
+                               f"{n_frames} frame(s) sharded by strip over {world} GPU(s)"),
                 "rays": "ray segments (primary + secondary closest-hit queries)",
                 "mprimary_per_s": prim / elapsed / 1e6,
                 "segments_per_primary": segs / prim,
-                "engine": ["linear scan, scene resident in LDS", "linear scan, scene streamed through LDS",
-                           "per-lane traversal of the reference BVH (exact nodes)",
-                           "per-lane traversal of the reference BVH (quantised nodes, exact leaf validation)",
-                           "per-lane traversal of the reference BVH (exact nodes resident in LDS)"][st.engine],
+                "engine": eng_names[st.engine],
                 "flags": args.flags,
                 "overlapped_steps": bool(args.overlap),
                 "pcie_inclusive": pcie,
@@ -265,18 +333,20 @@ def main():
                 "peak": PEAK_FP32_VALU_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved_tflops / PEAK_FP32_VALU_TFLOPS,
-                "traffic": traffic,
-                "kernel": "rtk::rt_tile_kernel",
+                "traffic": traffic_rec.get("bytes_per_launch") if isinstance(traffic_rec, dict) else None,
+                "traffic_source": traffic_rec.get("source") if isinstance(traffic_rec, dict) else None,
+                "kernel": "rtk::rt_tile_kernel (" + eng_names[st.engine] + ")",
                 "avg_launch_ms": avg_launch_s * 1e3,
                 "launches": launches,
-                "algorithmic_flops_per_launch": segs_per_launch * FLOPS_PER_TEST * n_sph,
-                "note": "SURVEY 8(d): neither HBM nor MFMA binds this path; FP32 VALU does. "
-                        "achieved = ray segments/launch x 20 flop x N spheres / HIP-event launch time, i.e. the "
-                        "ALGORITHMIC flops of the reference's linear closest-hit; the BVH-traversal engine reaches the "
-                        "same bit-exact result with O(log N) tests per segment, so its frac is an algorithmic rate, "
-                        "not an FMA issue rate (--flags 32 benches the linear engine: frac = issue-rate bound)",
-                # from the committed PMC pass of this workload (profiles/valu_issue.json), not measured live:
-                # share of the SIMDs' cycles in which a VALU instruction of this kernel holds the issue slot
+                "executed_flops_per_launch": flops_per_launch,
+                "work": work,
+                "note": "SURVEY 8(d): neither HBM nor MFMA binds this path; the FP32 vector pipe does.  achieved = the flops "
+                        "of the slab and root tests the timed engine executes (counted, not modelled) / HIP-event launch "
+                        "time; the rest of the kernel's instructions (control, LDS, 64-bit integer RNG, IEEE div/sqrt "
+                        "expansions) are not flops and are not counted",
+                # NOT a hardware fraction: what a linear scan would have to sustain to match this launch time
+                "algorithmic_equiv_tflops": algorithmic_equiv_tflops,
+                # committed PMC pass of this workload: VALU issue share of the SIMD cycles, active lanes per instruction
                 "valu_issue": issue,
                 "hbm": {
                     "algorithmic_bytes_per_launch": hbm_bytes_per_launch,
@@ -285,7 +355,9 @@ def main():
                     "frac": hbm_bytes_per_launch / avg_launch_s / 1e9 / PEAK_HBM_GBS,
                 },
             },
+            "roofline_linear": linear,
         }
+        assert 0.0 < line["roofline"]["frac"] <= 1.0, line["roofline"]
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_scale)
         else:

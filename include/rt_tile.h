@@ -35,7 +35,7 @@ extern "C" {
 #define RT_API __attribute__((visibility("default")))
 #endif
 
-#define RT_ABI_VERSION 1u
+#define RT_ABI_VERSION 2u      /* 2: rt_tile_stats.node_steps appended */
 
 /* ---- status codes --------------------------------------------------------------- */
 typedef enum rt_status {
@@ -106,7 +106,10 @@ enum {
     RT_FLAG_QUANT_NODES = 1u << 7,
     /* A tree whose exact nodes fit a CU's LDS (about 1000 primitives) is walked from an LDS-resident copy by default;
      * this flag keeps the nodes in HBM / L2 (A/B runs, tests).  Identical images. */
-    RT_FLAG_NO_LDS_TREE = 1u << 8
+    RT_FLAG_NO_LDS_TREE = 1u << 8,
+    /* Measurement aid (bench.py's roofline object): run the traversal kernel's counting twin, which also counts the
+     * internal BVH nodes visited (rt_tile_stats.node_steps).  Same image; a few per cent slower, never the timed launch. */
+    RT_FLAG_COUNT_STEPS = 1u << 9
 };
 
 typedef struct rt_tile_request {
@@ -146,6 +149,9 @@ typedef struct rt_tile_stats {
                                    3 BVH traversal (quantised nodes + exact leaf validation),
                                    4 BVH traversal, exact nodes resident in LDS */
     uint32_t broad_form;        /* linear engines: 0 = oc form, 1 = expanded form   */
+    uint64_t node_steps;        /* traversal engines under RT_FLAG_COUNT_STEPS: internal BVH nodes visited
+                                   (each = two child-box slab tests); 0 otherwise.  broad_candidates = leaves
+                                   reached = exact root tests for these engines */
 } rt_tile_stats;
 
 /* ---- lifecycle ------------------------------------------------------------------ */

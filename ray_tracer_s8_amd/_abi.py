@@ -32,6 +32,7 @@ RT_FLAG_LINEAR_SCAN = 32
 RT_FLAG_EXACT_NODES = 64
 RT_FLAG_QUANT_NODES = 128
 RT_FLAG_NO_LDS_TREE = 256
+RT_FLAG_COUNT_STEPS = 512
 RT_MAX_BOUNCES = 62
 
 # numpy dtypes with the exact layout of rt_sphere / rt_triangle (no padding)
@@ -70,10 +71,12 @@ class TileStats(C.Structure):
         ("broad_candidates", C.c_uint64), ("exact_fallbacks", C.c_uint64),
         ("kernel_ms", C.c_float), ("h2d_ms", C.c_float), ("d2h_ms", C.c_float),
         ("n_launches", C.c_uint32), ("engine", C.c_uint32), ("broad_form", C.c_uint32),
+        ("node_steps", C.c_uint64),
     ]
 
 
 assert C.sizeof(TileRequest) == 64
+assert C.sizeof(TileStats) == 64
 
 
 def default_request(**kw) -> TileRequest:

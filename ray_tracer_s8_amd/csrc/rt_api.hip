@@ -202,10 +202,10 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     size_t lt_mat = 0, lt_emis = 0, lt_geom = 0;      // bytes staged besides the nodes (0 = stays in HBM)
     const size_t lt_lane = ((size_t)rtk::MAXL_LTREE + (size_t)(rq->max_bounces + 1) + (size_t)(sc->bvh_depth + 2)) * sizeof(uint16_t);
     if (traverse && !qnodes && ltree_env && !(rq->flags & RT_FLAG_NO_LDS_TREE) && sc->n_internal > 0 && n_prims <= 0x7fffu) {
-        const size_t fixed = ((size_t)sc->n_internal + 1) * 64 + lt_lane * rtk::LTREE_BLOCK;   // + the DONE node
+        const size_t fixed = ((size_t)sc->n_internal + 1) * (rtk::LNODE_DW * 4) + lt_lane * rtk::LTREE_BLOCK;   // + the DONE node
         if (fixed <= LDS_LIMIT) {
             ltree = true;
-            static const int extras = [] { const char* e = getenv("RT_LDS_TREE_EXTRAS"); return e ? atoi(e) : 7; }();   // bit 0 mat, 1 emis, 2 geom
+            static const int extras = [] { const char* e = getenv("RT_LDS_TREE_EXTRAS"); return e ? atoi(e) : 0; }();   // bit 0 mat, 1 emis, 2 geom (c3: no gain from any of them)
             size_t used = fixed;
             if ((extras & 1) && used + (size_t)n_prims * 16 <= LDS_LIMIT) { lt_mat = (size_t)n_prims * 16; used += lt_mat; }
             if ((extras & 2) && used + (size_t)n_prims * 4 <= LDS_LIMIT) { lt_emis = (size_t)n_prims * 4; used += lt_emis; }
@@ -260,7 +260,7 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     const int bs = ltree ? rtk::LTREE_BLOCK : rtk::BLOCK;
     if (ltree) {
         // [nodes][mat][geom][emis][leaf lists u16][path u16][stack u16]
-        size_t off = ((size_t)sc->n_internal + 1) * 64;
+        size_t off = (((size_t)sc->n_internal + 1) * (rtk::LNODE_DW * 4) + 15) & ~(size_t)15;
         if (lt_mat) { p.lds_mat_off = (uint32_t)off; off += lt_mat; }
         if (lt_geom) { p.lds_geom_off = (uint32_t)off; off += lt_geom; }
         if (lt_emis) { p.lds_emis_off = (uint32_t)off; off += (lt_emis + 15) & ~(size_t)15; }
@@ -327,7 +327,8 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
 
     // persistent grid: as many workgroups as the chip holds at this LDS/VGPR budget
     int per_cu = 0;
-    const rtk::KernelFn kern = traverse ? rtk::kernel_traverse(ltree ? 3 : qnodes ? (capped ? 2 : 1) : 0) : rtk::kernel_linear(streamed, expanded);
+    const bool count_steps = traverse && (rq->flags & RT_FLAG_COUNT_STEPS);
+    const rtk::KernelFn kern = traverse ? rtk::kernel_traverse(ltree ? 3 : qnodes ? (capped ? 2 : 1) : 0, count_steps) : rtk::kernel_linear(streamed, expanded);
     HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, bs, lds));
     if (per_cu < 1) per_cu = 1;
     static const bool verbose = getenv("RT_VERBOSE") != nullptr;
@@ -398,6 +399,7 @@ int collect_locked(rt_scene* sc, rt_tile_stats* st) {
         st->d2h_ms = 0.f;
         st->engine = sc->last_engine;
         st->broad_form = sc->last_form;
+        st->node_steps = c[3];
     }
     sc->primary_rays = 0;
     sc->h2d_ms = 0.f;
@@ -489,8 +491,9 @@ static int ensure_ctx(DeviceCtx* c) {
             HIPCHK(hipFuncSetAttribute((const void*)rtk::kernel_linear(streamed != 0, expanded != 0),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
     for (int variant = 0; variant < 4; variant++)
-        HIPCHK(hipFuncSetAttribute((const void*)rtk::kernel_traverse(variant),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
+        for (int stats = 0; stats < 2; stats++)
+            HIPCHK(hipFuncSetAttribute((const void*)rtk::kernel_traverse(variant, stats != 0),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
     hipStream_t st = nullptr, cs = nullptr;
     HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
@@ -993,6 +996,7 @@ RT_API int rt_render_frame(const int* devices, int n_devices, const rt_tile_requ
         tot.primary_rays += sts[w].primary_rays;
         tot.broad_candidates += sts[w].broad_candidates;
         tot.exact_fallbacks += sts[w].exact_fallbacks;
+        tot.node_steps += sts[w].node_steps;
         tot.kernel_ms = std::max(tot.kernel_ms, sts[w].kernel_ms);   // devices run concurrently
         tot.h2d_ms = std::max(tot.h2d_ms, sts[w].h2d_ms);
         tot.d2h_ms = std::max(tot.d2h_ms, sts[w].d2h_ms);

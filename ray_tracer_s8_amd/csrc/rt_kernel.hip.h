@@ -68,6 +68,7 @@ constexpr int TRAV_STACK = 64;   // traversal stack entries per lane (host falls
 constexpr int MAXL = RT_MAXL;    // leaf-candidate slots per lane in traversal mode (flushed when full)
 constexpr int MINL = RT_MINL;
 constexpr int MAXL_EXACT = 7;     // exact-node kernel: fixed (see the kernel)
+constexpr int LNODE_DW = 20;      // LDS-tree kernel: dwords per staged node (see the staging code)
 constexpr int MAXL_LTREE = 12;    // LDS-tree kernel (16-bit entries): a block of RT_STEPS_PER_CHECK appends always fits
 constexpr uint32_t LEAF_BIT = 0x80000000u;
 
@@ -466,7 +467,7 @@ __device__ __forceinline__ const T& at32(const T* __restrict__ base, uint32_t i)
 // through LDS in chunks; 2 = per-lane traversal of the reference BVH (exact 64-byte nodes); 3 = the same walk over
 // 32-byte nodes whose boxes are rounded outwards onto a 16-bit grid, every reached leaf being validated with the
 // reference's exact own-leaf AABB test.
-template <int ISECT, bool EXPANDED, int BS = BLOCK>
+template <int ISECT, bool EXPANDED, int BS = BLOCK, bool STATS = false>
 __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 3 ? RT_MINWAVES_QTRAV : ISECT == 2 ? RT_MINWAVES_TRAV : RT_MINWAVES) void rt_tile_kernel(const KParams p) {
     constexpr int BLOCK = BS;                        // threads per workgroup = stride of the per-lane LDS arrays
     constexpr bool STREAMED = (ISECT == 1);
@@ -503,20 +504,28 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 3 ? R
     }
 
     if (LTREE) {
-        // stage the whole tree once per workgroup; child references become 16-bit (leaf flag 0x8000)
-        float4* ln = reinterpret_cast<float4*>(lds_raw + p.lds_node_off);
-        for (uint32_t i = tid; i < 4u * p.n_internal; i += BLOCK) {
-            float4 v = p.trav[i];
-            if ((i & 2u) == 0) {                                   // (l_lo, left) and (l_hi, right)
-                uint32_t r = __float_as_uint(v.w);
-                if (r & LEAF_BIT) r = 0x8000u | (r & 0x7fffu);
-                v.w = __uint_as_float(r);
+        // Stage the whole tree once per workgroup, 80 bytes per node, laid out for SIGN-SELECTED plane fetches: for
+        // each axis and child the three dwords (lo, hi, lo), so that a two-dword read at dword offset s = (d.axis < 0)
+        // returns (near, far) = (aabb[sign], aabb[1 - sign]) — literally ray.rs:175-176 — with no min / max / select in
+        // the step.  Dwords: l.x 0-2, r.x 3-5, l.y 6-8, r.y 9-11, l.z 12-14, r.z 15-17, 18 = left | right << 16 (16-bit
+        // references, leaf flag 0x8000).  Entry n_internal is node DONE: NaN planes, entered by no ray.
+        float* ln = reinterpret_cast<float*>(lds_raw + p.lds_node_off);
+        for (uint32_t n = tid; n <= p.n_internal; n += BLOCK) {
+            float* q = ln + LNODE_DW * n;
+            if (n < p.n_internal) {
+                const float4 a0 = p.trav[4u * n], a1 = p.trav[4u * n + 1], a2 = p.trav[4u * n + 2], a3 = p.trav[4u * n + 3];
+                // a child reference is 0x8000 | primitive, or the child node's offset in 16-byte units (= 5 * index)
+                auto ref16 = [](uint32_t r) { return (r & LEAF_BIT) ? (0x8000u | (r & 0x7fffu)) : r * (uint32_t)(LNODE_DW / 4); };
+                q[0] = a0.x; q[1] = a1.x; q[2] = a0.x;   q[3] = a2.x; q[4] = a3.x; q[5] = a2.x;
+                q[6] = a0.y; q[7] = a1.y; q[8] = a0.y;   q[9] = a2.y; q[10] = a3.y; q[11] = a2.y;
+                q[12] = a0.z; q[13] = a1.z; q[14] = a0.z; q[15] = a2.z; q[16] = a3.z; q[17] = a2.z;
+                q[18] = __uint_as_float(ref16(__float_as_uint(a0.w)) | (ref16(__float_as_uint(a1.w)) << 16));
+            } else {
+                const float qn = __builtin_nanf("");
+                for (int i = 0; i < 18; i++) q[i] = qn;
+                q[18] = __uint_as_float((p.n_internal * (uint32_t)(LNODE_DW / 4)) * 0x10001u);
             }
-            ln[i] = v;
-        }
-        if (tid < 4) {                                             // node DONE: NaN boxes, entered by no ray
-            const float qn = __builtin_nanf("");
-            ln[4u * p.n_internal + tid] = make_float4(qn, qn, qn, __uint_as_float(p.n_internal));
+            q[19] = 0.f;
         }
         const uint32_t np = p.n_sph + p.n_tri;
         if (p.lds_mat_off != 0xffffffffu) {
@@ -533,7 +542,7 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 3 ? R
         }
         __syncthreads();
     }
-    const float4* const lnodes = reinterpret_cast<const float4*>(lds_raw + p.lds_node_off);
+    const float* const lnodes = reinterpret_cast<const float*>(lds_raw + p.lds_node_off);
     // material / geometry fetch: LDS copy when the launch staged one, else HBM (L2)
     auto mat_at = [&](uint32_t i) -> float4 {
         if (LTREE && p.lds_mat_off != 0xffffffffu) return reinterpret_cast<const float4*>(lds_raw + p.lds_mat_off)[i];
@@ -575,6 +584,7 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 3 ? R
     // per-lane statistics.  Traversal kernels (register-bound): 32-bit, drained into the 64-bit totals before they can wrap
     using Cnt = typename std::conditional<(ISECT >= 2), uint32_t, unsigned long long>::type;
     Cnt n_seg = 0, n_cand = 0, n_fall = 0;
+    Cnt n_int = 0;               // STATS variants (RT_FLAG_COUNT_STEPS): internal nodes visited = pairs of slab tests
     // ---- closest-hit query state.  The linear engines finish a query inside one loop iteration; the traversal
     // engine keeps it across iterations (in_trav) so that lanes whose traversal ended can be refilled while
     // stragglers keep walking.
@@ -590,25 +600,29 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 3 ? R
     bool qfin = false;                       // QNODES: this lane may use the quantised boxes
     uint32_t* lc32 = reinterpret_cast<uint32_t*>(lds_raw + p.lds_cand_off);     // TRAVERSE: leaf candidates (u32)
     uint32_t* lstack = reinterpret_cast<uint32_t*>(lds_raw + p.lds_stack_off);   // TRAVERSE: per-lane stack
+    uint32_t sgx = 0, sgy = 0, sgz = 0;      // LTREE: (direction.axis < 0) of the current query, ray.rs:139-141
     uint16_t* lc16 = reinterpret_cast<uint16_t*>(lds_raw + p.lds_cand_off);     // LTREE: both 16-bit
     uint16_t* lstack16 = reinterpret_cast<uint16_t*>(lds_raw + p.lds_stack_off);
 
-    if (BFSTEP) lstack16[tid] = (uint16_t)p.n_internal;  // stack slot 0: popping an empty stack yields DONE
+    if (BFSTEP) lstack16[tid] = (uint16_t)(p.n_internal * (uint32_t)(LNODE_DW / 4));  // stack slot 0: popping an empty stack yields DONE
 
     auto drain_counters = [&]() {
         const unsigned long long ws = wave_sum(n_seg), wc = wave_sum(n_cand), wf = wave_sum(n_fall);
+        const unsigned long long wi = STATS ? wave_sum(n_int) : 0ull;
         if (lane == (int)__builtin_ctzll(__ballot(true))) {
             atomicAdd(&p.counters[0], ws);
             atomicAdd(&p.counters[1], wc);
             atomicAdd(&p.counters[2], wf);
+            if (STATS) atomicAdd(&p.counters[3], wi);
         }
         n_seg = n_cand = n_fall = 0;
+        n_int = 0;
     };
     TDECL;
     for (;;) {
         WCOUNT(0);
         TSTAMP(5);
-        if (TRAVERSE && __ballot(((n_seg | n_cand | n_fall) & 0x80000000u) != 0)) drain_counters();
+        if (TRAVERSE && __ballot(((n_seg | n_cand | n_fall | n_int) & 0x80000000u) != 0)) drain_counters();
         // ================= pixel acquisition: lanes pull pixels of the wave's current tile
         {
             bool need = !have_pixel && !retired;
@@ -739,6 +753,11 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 3 ? R
                 qfin = aux.finite && ax < big && ay < big && az < big && ax > tiny && ay > tiny && az > tiny &&
                        __builtin_fabsf(og.x) < 0x1p18f && __builtin_fabsf(og.y) < 0x1p18f && __builtin_fabsf(og.z) < 0x1p18f;
             }
+            if (LTREE) {
+                sgx = aux.sx ? 1u : 0u;
+                sgy = aux.sy ? 1u : 0u;
+                sgz = aux.sz ? 1u : 0u;
+            }
             if (TRAVERSE) {
                 t_ref = p.root_ref;
                 t_sp = BFSTEP ? 1u : 0u;                     // slot 0 of the branch-free step's stack holds the DONE sentinel
@@ -820,29 +839,46 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 3 ? R
             //   * the leaf list has room for a whole block of appends (checked between blocks): no fullness test.
             // The crate's literal slab test (a +-0 direction component, or RT_FLAG_FULL_CHAIN) is chosen per BLOCK of
             // steps for the whole wave: it is the reference's own test, valid for every lane.
-            const uint32_t DONE = p.n_internal;
+            const uint32_t DONE = p.n_internal * (uint32_t)(LNODE_DW / 4);      // node references are offsets in 16-byte units
             constexpr int STEPS = RT_STEPS_PER_CHECK;
             static_assert(MAXL_LTREE > STEPS, "the leaf list must take a block of appends");
             auto step = [&](auto slow_tag) {
                 constexpr bool SLOW = decltype(slow_tag)::value;
                 const bool is_leaf = t_ref > 0x7fffu;
                 const uint32_t ni = is_leaf ? DONE : t_ref;
+                if (STATS) n_int += (ni != DONE) ? 1u : 0u;
                 const uint32_t top = (uint32_t)lstack16[(t_sp - 1u) * BLOCK + tid];
                 WCOUNT(5);
                 LCOUNT(5);
                 uint16_t* const dst = is_leaf ? &lc16[t_cnt * BLOCK + tid] : &lstack16[t_sp * BLOCK + tid];
                 *dst = (uint16_t)t_ref;                          // (the flush masks the leaf flag off)
-                const float4* __restrict__ nd = lnodes + (ni << 2);
-                const float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
+                // Ray::intersects_aabb (ray.rs:174-194) on both child boxes; (near, far) planes fetched by sign
+                const float* __restrict__ nd = lnodes + (ni << 2);
+                const float* __restrict__ fx = nd + sgx;
+                const float* __restrict__ fy = nd + 6 + sgy;
+                const float* __restrict__ fz = nd + 12 + sgz;
+                float p0 = fx[0], p1 = fx[1], p2 = fx[3], p3 = fx[4], p4 = fy[0], p5 = fy[1], p6 = fy[3], p7 = fy[4];
+                float p8 = fz[0], p9 = fz[1], p10 = fz[3], p11 = fz[4];
+                uint32_t refs = __float_as_uint(nd[18]);
+                // all seven reads in flight before the first use (the scheduler, short of registers, serialised them)
+                asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7), "+v"(p8),
+                             "+v"(p9), "+v"(p10), "+v"(p11), "+v"(refs));
+                const float lxn = (p0 - o.x) * aux.inv.x, lxf = (p1 - o.x) * aux.inv.x;
+                const float rxn = (p2 - o.x) * aux.inv.x, rxf = (p3 - o.x) * aux.inv.x;
+                const float lyn = (p4 - o.y) * aux.inv.y, lyf = (p5 - o.y) * aux.inv.y;
+                const float ryn = (p6 - o.y) * aux.inv.y, ryf = (p7 - o.y) * aux.inv.y;
+                const float lzn = (p8 - o.z) * aux.inv.z, lzf = (p9 - o.z) * aux.inv.z;
+                const float rzn = (p10 - o.z) * aux.inv.z, rzf = (p11 - o.z) * aux.inv.z;
                 bool hl, hr;
-                if (SLOW) {                                      // the crate's literal form (ray.rs:174-194)
-                    hl = intersects_aabb(o, aux, n0, n1);
-                    hr = intersects_aabb(o, aux, n2, n3);
-                } else {
-                    hl = intersects_aabb_finite(o, aux, n0, n1);
-                    hr = intersects_aabb_finite(o, aux, n2, n3);
+                if (SLOW) {                                      // the crate's min / max (ray.rs:81-112): NaN-aware order
+                    hl = rmax(rmax(rmax(lxn, lyn), lzn), 0.0f) <= rmin(rmin(lxf, lyf), lzf);
+                    hr = rmax(rmax(rmax(rxn, ryn), rzn), 0.0f) <= rmin(rmin(rxf, ryf), rzf);
+                } else {                                         // finite inverse direction: no NaN can arise, and min / max
+                    // differ from the crate's forms only in the sign of a zero, which no comparison sees
+                    hl = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(lxn, lyn), lzn), 0.0f) <= __builtin_fminf(__builtin_fminf(lxf, lyf), lzf);
+                    hr = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(rxn, ryn), rzn), 0.0f) <= __builtin_fminf(__builtin_fminf(rxf, ryf), rzf);
                 }
-                const uint32_t cl = __float_as_uint(n0.w), cr = __float_as_uint(n1.w);
+                const uint32_t cl = refs & 0xffffu, cr = refs >> 16;
                 lstack16[t_sp * BLOCK + tid] = (uint16_t)cr;     // right subtree after the whole left subtree
                 const bool any = hl || hr;
                 t_ref = any ? (hl ? cl : cr) : top;
@@ -903,6 +939,7 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 3 ? R
                     } else {
                         bool hl, hr;
                         uint32_t cl, cr;
+                        if (STATS) n_int++;
                         if (QNODES) {
                             // (32-bit byte offset from the uniform base: one shift and the scalar-base addressing mode)
                             const uint4* __restrict__ nq = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.travq) + (t_ref << 5));
@@ -1242,8 +1279,9 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 3 ? R
 // The kernels are instantiated in rt_kernels_lin.hip / rt_kernels_trav.hip; the host side (rt_api.hip) gets them here.
 using KernelFn = void (*)(const KParams);
 KernelFn kernel_linear(bool streamed, bool expanded);
-KernelFn kernel_traverse(int variant);   // 0: exact nodes, 1: quantised nodes, 2: quantised nodes with the capped LDS stack,
+KernelFn kernel_traverse(int variant, bool stats = false);   // 0: exact nodes, 1: quantised nodes, 2: quantised nodes with the capped LDS stack,
                                          // 3: exact nodes, whole tree resident in LDS (1024-thread workgroups)
+                                         // stats: the variant that also counts node visits (RT_FLAG_COUNT_STEPS)
 constexpr int LTREE_BLOCK = 1024;
 
 }  // namespace rtk

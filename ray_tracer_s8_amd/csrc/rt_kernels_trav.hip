@@ -5,7 +5,13 @@
 #include "rt_kernel.hip.h"
 
 namespace rtk {
-KernelFn kernel_traverse(int variant) {
+KernelFn kernel_traverse(int variant, bool stats) {
+    if (stats) {
+        if (variant == 3) return rt_tile_kernel<5, false, LTREE_BLOCK, true>;
+        return variant == 2   ? rt_tile_kernel<4, false, BLOCK, true>
+               : variant == 1 ? rt_tile_kernel<3, false, BLOCK, true>
+                              : rt_tile_kernel<2, false, BLOCK, true>;
+    }
     if (variant == 3) return rt_tile_kernel<5, false, LTREE_BLOCK>;
     return variant == 2 ? rt_tile_kernel<4, false> : variant == 1 ? rt_tile_kernel<3, false> : rt_tile_kernel<2, false>;
 }

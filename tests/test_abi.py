@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     lib = _abi.load()
     for name in declared_functions():
         assert hasattr(lib, name), f"{name} declared in rt_tile.h but not exported by librt_s8.so"
-    assert lib.rt_abi_version() == 1
+    assert lib.rt_abi_version() == 2
 
 
 def test_header_cites_reference_lines():
@@ -43,7 +43,7 @@ def test_header_cites_reference_lines():
 def test_struct_layouts_match_header():
     assert C.sizeof(_abi.TileRequest) == 64
     assert _abi.SPHERE_DTYPE.itemsize == 36 and _abi.TRIANGLE_DTYPE.itemsize == 56
-    assert C.sizeof(_abi.TileStats) == 56
+    assert C.sizeof(_abi.TileStats) == 64
     offs = {n: getattr(_abi.TileRequest, n).offset for n, _ in _abi.TileRequest._fields_}
     assert offs["width"] == 0 and offs["spp"] == 16 and offs["aperture"] == 24 and offs["seed"] == 48 and offs["flags"] == 56
 
