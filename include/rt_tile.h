@@ -53,6 +53,8 @@ typedef enum rt_status {
 } rt_status;
 
 #define RT_MAX_BOUNCES 62u      /* path stack depth limit (reference literal is 10)           */
+#define RT_MAX_PRIMITIVES 0x3ffffffu /* spheres + triangles per scene: the kernels address nodes, geometry and
+                                   materials with 32-bit byte offsets (64 B per tree node)    */
 
 /* ---- scene primitives ----------------------------------------------------------- */
 
@@ -159,6 +161,7 @@ typedef struct rt_tile_stats {
 /* Enumerate HIP devices, create one context (stream + events + counters) per device.
  * *n_devices may be NULL.  Returns RT_ERR_NO_DEVICE if none: there is NO CPU fallback. */
 RT_API int rt_init(int* n_devices);
+/* Refused (no effect; rt_last_error() says so) while any rt_scene is alive: destroy the scenes first. */
 RT_API void rt_shutdown(void);
 RT_API uint32_t rt_abi_version(void);
 RT_API const char* rt_strerror(int status);
@@ -206,7 +209,9 @@ RT_API int rt_scene_render_tile(rt_scene* scene, const rt_tile_request* req,
 /* Asynchronous, device-resident output: enqueue the strip on `hip_stream`
  * (a hipStream_t; NULL = the scene's own stream) writing RGB8 to device memory
  * d_out_rgb (>= rt_tile_bytes) and, if non-NULL, floats to d_out_f32.
- * Counters and HIP-event timings accumulate in the scene until rt_scene_collect(). */
+ * Counters and HIP-event timings accumulate in the scene until rt_scene_collect().
+ * Launches of one scene may be spread over several streams and overlap; the library chains only
+ * those that share per-scene scratch (the capped-stack walk of trees deeper than the LDS stack). */
 RT_API int rt_scene_render_tile_device(rt_scene* scene, const rt_tile_request* req,
                                        void* d_out_rgb, size_t out_len,
                                        void* d_out_f32, void* hip_stream);
@@ -231,9 +236,15 @@ RT_API int rt_scene_collect(rt_scene* scene, rt_tile_stats* stats);
 
 /* ---- whole frame: replaces controller dispatch + assembly ----------------------- */
 /* (controller main.rs:47-75 `for division_no in 0..divisions` and :109-115 stitch).
- * Strip k goes to devices[k % n_devices] (one host thread + stream per device), the
- * RGB8 strips are stitched by division_no into out_rgb (H*W*3).  devices==NULL means
- * all devices.  req->division_no is ignored.  height % divisions must be 0. */
+ * The world's host-side preparation (device layouts, the candidate-filter BVH) is done once and
+ * uploaded to every device; one host thread per device renders its strips and the RGB8 strips
+ * are stitched by division_no into out_rgb (H*W*3), which is page-locked for the duration of
+ * the call so that the downloads run as DMA under the kernels.  Strip assignment: strip k goes
+ * to devices[k % n_devices], all strips of a device in one launch (default); with the
+ * environment variable RT_FRAME_QUEUE=1 the devices instead pull strips one at a time, bottom
+ * of the frame (the expensive strips) first, from a shared host-atomic queue, two launches in
+ * flight per device.  Same bytes either way.  devices==NULL means all devices.
+ * req->division_no is ignored.  height % divisions must be 0. */
 RT_API int rt_render_frame(const int* devices, int n_devices, const rt_tile_request* req,
                            const rt_sphere* spheres, uint32_t n_spheres,
                            const rt_triangle* triangles, uint32_t n_triangles,

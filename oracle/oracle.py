@@ -177,3 +177,29 @@ def bvh_traverse_boxes(boxes, origin, direction):
     n = load().rt_oracle_bvh_traverse_boxes(_p(b), C.c_uint32(len(b)), _p(_f3(origin)), _p(_f3(direction)), _p(out),
                                             C.c_uint32(len(out)), C.byref(nn))
     return out[:n].tolist(), nn.value
+
+
+def aabb_kat(a6, b6, point):
+    """size, center, surface_area, largest_axis, is_empty, join(a, b), grow(a, point) of the oracle's AABB helpers."""
+    out = np.zeros(21, np.float32)
+    load().rt_oracle_aabb_kat(_p(np.ascontiguousarray(a6, np.float32)), _p(np.ascontiguousarray(b6, np.float32)),
+                              _p(_f3(point)), _p(out))
+    return {"size": out[0:3], "center": out[3:6], "surface_area": float(out[6]), "largest_axis": int(out[7]),
+            "is_empty": bool(out[8]), "join": out[9:15], "grow": out[15:21]}
+
+
+def aabb_empty():
+    out = np.zeros(6, np.float32)
+    load().rt_oracle_aabb_empty(_p(out))
+    return out
+
+
+def axis_get(v, axis: int) -> float:
+    lib = load()
+    lib.rt_oracle_axis_get.restype = C.c_float
+    return float(lib.rt_oracle_axis_get(_p(_f3(v)), C.c_int(axis)))
+
+
+def ray_intersects_aabb(origin, direction, box6) -> bool:
+    return bool(load().rt_oracle_ray_intersects_aabb(_p(_f3(origin)), _p(_f3(direction)),
+                                                     _p(np.ascontiguousarray(box6, np.float32))))

@@ -923,6 +923,37 @@ __attribute__((visibility("default"))) void rt_oracle_camera_consts(const rt_til
                   c.horizontal.z,        c.vertical.x,          c.vertical.y,          c.vertical.z};
     std::memcpy(out, v, sizeof v);
 }
+// AABB helpers on raw boxes (6 floats: min xyz, max xyz), for the reference's own doc-test vectors (B/aabb.rs:453,474,
+// 520,565; B/axis.rs:20,33).  out[0..2] size, [3..5] center, [6] surface_area, [7] largest_axis, [8] is_empty,
+// [9..14] join(a, b), [15..20] grow(a, point)
+__attribute__((visibility("default"))) void rt_oracle_aabb_kat(const float* a6, const float* b6, const float* pt3,
+                                                               float* out) {
+    const AABB a{v3(a6[0], a6[1], a6[2]), v3(a6[3], a6[4], a6[5])};
+    const AABB b{v3(b6[0], b6[1], b6[2]), v3(b6[3], b6[4], b6[5])};
+    const V3 sz = aabb_size(a), c = aabb_center(a);
+    out[0] = sz.x; out[1] = sz.y; out[2] = sz.z;
+    out[3] = c.x; out[4] = c.y; out[5] = c.z;
+    out[6] = aabb_surface_area(a);
+    out[7] = (float)aabb_largest_axis(a);
+    out[8] = aabb_is_empty(a) ? 1.0f : 0.0f;
+    const AABB j = aabb_join(a, b), g = aabb_grow(a, arr3(pt3));
+    const float jj[12] = {j.mn.x, j.mn.y, j.mn.z, j.mx.x, j.mx.y, j.mx.z, g.mn.x, g.mn.y, g.mn.z, g.mx.x, g.mx.y, g.mx.z};
+    std::memcpy(out + 9, jj, sizeof jj);
+}
+// AABB::empty() (B/aabb.rs:124-129) as 6 floats
+__attribute__((visibility("default"))) void rt_oracle_aabb_empty(float* out6) {
+    const AABB e = aabb_empty();
+    const float v[6] = {e.mn.x, e.mn.y, e.mn.z, e.mx.x, e.mx.y, e.mx.z};
+    std::memcpy(out6, v, sizeof v);
+}
+// component of a vector by Axis (B/axis.rs:36-46: X = 0, Y = 1, Z = 2)
+__attribute__((visibility("default"))) float rt_oracle_axis_get(const float* v3p, int axis) { return axis_of(arr3(v3p), axis); }
+// Ray::new(origin, direction).intersects_aabb(box) (B/ray.rs:133-143, 174-194)
+__attribute__((visibility("default"))) int rt_oracle_ray_intersects_aabb(const float* origin, const float* dir,
+                                                                         const float* box6) {
+    const Ray r = ray_new(arr3(origin), arr3(dir));
+    return intersects_aabb(r, AABB{v3(box6[0], box6[1], box6[2]), v3(box6[3], box6[4], box6[5])}) ? 1 : 0;
+}
 // BVH over raw AABBs (n boxes, 6 floats each: min xyz, max xyz); traverse one ray; returns
 // number of candidate shape indices written to out_idx (DFS leaf order), capacity cap.
 __attribute__((visibility("default"))) int rt_oracle_bvh_traverse_boxes(const float* boxes, uint32_t n,

@@ -12,7 +12,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <thread>
 #include <vector>
@@ -28,6 +31,31 @@ thread_local std::string g_err;
 int fail(int code, const std::string& msg) {
     g_err = msg;
     return code;
+}
+
+// Nothing may unwind across the C boundary (rt_tile.h: "never throws or aborts"): every extern "C" entry point runs its
+// body through this.  The bodies allocate (std::vector, std::string, std::thread); a failed allocation becomes
+// RT_ERR_OOM, anything else RT_ERR_HIP with the exception's text.  Setting the message must not throw either.
+void set_err_noexcept(const char* what) noexcept {
+    try {
+        g_err = what;
+    } catch (...) {
+    }
+}
+template <class F>
+int guarded(F&& body) noexcept {
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        set_err_noexcept("host allocation failed");
+        return RT_ERR_OOM;
+    } catch (const std::exception& e) {
+        set_err_noexcept(e.what());
+        return RT_ERR_HIP;
+    } catch (...) {
+        set_err_noexcept("internal error");
+        return RT_ERR_HIP;
+    }
 }
 
 #define HIPCHK(expr)                                                                                  \
@@ -50,6 +78,7 @@ struct DeviceCtx {
 std::mutex g_mu;
 bool g_init = false;
 std::vector<DeviceCtx*> g_ctx;
+std::atomic<int> g_live_scenes{0};   // rt_shutdown is refused while any scene is alive (scenes point at their DeviceCtx)
 
 constexpr size_t LDS_LIMIT = 160 * 1024 - 1024;   // dynamic LDS budget; 1 KiB left for the kernels' static LDS
 constexpr uint32_t RESIDENT_MAX = rtk::CHUNK;   // spheres kept wholly in LDS
@@ -76,6 +105,8 @@ struct rt_scene {
     float4* d_trav = nullptr;      // rtbvh::TravNode[]
     uint32_t* d_stack_ovf = nullptr;   // quantised-node kernel: stack entries beyond the LDS part, [entry][thread]
     size_t stack_ovf_words = 0;
+    hipEvent_t ovf_done = nullptr;     // end of the last launch that used d_stack_ovf: the area is one per scene, so such
+                                       // launches are chained even when the caller spreads them over several streams
     uint4* d_travq = nullptr;      // rtbvh::QNode[] (quantised twin)
     float4* d_geom_r = nullptr;    // (cx,cy,cz,radius)
     rtbvh::QGrid grid;
@@ -201,7 +232,8 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     bool ltree = false;
     size_t lt_mat = 0, lt_emis = 0, lt_geom = 0;      // bytes staged besides the nodes (0 = stays in HBM)
     const size_t lt_lane = ((size_t)rtk::MAXL_LTREE + (size_t)(rq->max_bounces + 1) + (size_t)(sc->bvh_depth + 2)) * sizeof(uint16_t);
-    if (traverse && !qnodes && ltree_env && !(rq->flags & RT_FLAG_NO_LDS_TREE) && sc->n_internal > 0 && n_prims <= 0x7fffu) {
+    if (traverse && !qnodes && ltree_env && !(rq->flags & RT_FLAG_NO_LDS_TREE) && sc->n_internal > 0 && n_prims <= 0x7fffu &&
+        ((size_t)sc->n_internal + 1) * rtk::LNODE_DW < 0x8000u) {
         const size_t fixed = ((size_t)sc->n_internal + 1) * (rtk::LNODE_DW * 4) + lt_lane * rtk::LTREE_BLOCK;   // + the DONE node
         if (fixed <= LDS_LIMIT) {
             ltree = true;
@@ -235,10 +267,12 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
         const size_t per_wg = (160u * 1024u - 4096u) / 5u - 256u;     // 4 KiB of slack, 256 B static LDS
         const size_t fixed = path_bytes + (size_t)stack_need * rtk::BLOCK * sizeof(uint32_t);
         const size_t slot = (size_t)rtk::BLOCK * sizeof(uint32_t);
-        if (fixed + (size_t)rtk::MINL * slot <= per_wg) {
+        // (RT_FORCE_CAPPED / RT_STACK_LDS, read per launch: tests drive the capped-stack kernel with small trees)
+        const bool force_capped = [] { const char* e = getenv("RT_FORCE_CAPPED"); return e && atoi(e) != 0; }();
+        if (!force_capped && fixed + (size_t)rtk::MINL * slot <= per_wg) {
             maxl = (uint32_t)std::min<size_t>((size_t)rtk::MAXL, (per_wg - fixed) / slot);
         } else {
-            static const uint32_t cap = [] { const char* e = getenv("RT_STACK_LDS"); return e && atoi(e) > 0 ? (uint32_t)atoi(e) : STACK_LDS_MAX; }();
+            const uint32_t cap = [] { const char* e = getenv("RT_STACK_LDS"); return e && atoi(e) > 0 ? (uint32_t)atoi(e) : STACK_LDS_MAX; }();
             capped = stack_capped > cap;
             stack_lds = capped ? cap : stack_need;
         }
@@ -299,7 +333,8 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
         // refill threshold: long walks (large scenes) want finished lanes replaced sooner, short walks amortise the
         // per-round shading / ray-generation code over more finished lanes (tools/variants_q.sh sweeps)
         static const int forced = [] { const char* e = getenv("RT_REFILL_EIGHTHS"); return e ? atoi(e) : 0; }();
-        p.refill_eighths = forced > 0 ? (uint32_t)forced : (n_prims >= RT_QNODES_MIN_PRIMS ? 4u : 2u);
+        // (the LDS-tree kernel's steps are cheap against its per-round shading code: it refills latest, 1/8)
+        p.refill_eighths = forced > 0 ? (uint32_t)forced : (ltree ? 1u : n_prims >= RT_QNODES_MIN_PRIMS ? 4u : 2u);
     }
     p.leaf_of = sc->d_leaf_of;
     p.n_strips = n;
@@ -346,8 +381,7 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
         const size_t words = (size_t)(stack_capped - stack_lds) * p.ovf_stride;
         if (words > sc->stack_ovf_words) {
             if (sc->d_stack_ovf) {
-                HIPCHK(hipStreamSynchronize(stream));              // launches in flight may still use the old area
-                HIPCHK(hipStreamSynchronize(sc->ctx->stream));
+                if (sc->ovf_done) HIPCHK(hipEventSynchronize(sc->ovf_done));   // a launch in flight may still use the old area
                 (void)hipFree(sc->d_stack_ovf);
                 sc->d_stack_ovf = nullptr;
                 sc->stack_ovf_words = 0;
@@ -361,6 +395,10 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     EvPair ev;
     int rc = get_events(sc, ev);
     if (rc) return rc;
+    if (p.stack_ovf) {
+        if (sc->ovf_done) HIPCHK(hipStreamWaitEvent(stream, sc->ovf_done, 0));
+        else HIPCHK(hipEventCreateWithFlags(&sc->ovf_done, hipEventDisableTiming));
+    }
     HIPCHK(hipMemsetAsync(p.queue, 0, sizeof(unsigned long long), stream));
     HIPCHK(hipEventRecord(ev.a, stream));
     sc->last_engine = traverse ? (ltree ? 4u : qnodes ? 3u : 2u) : (streamed ? 1u : 0u);
@@ -368,6 +406,7 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     hipLaunchKernelGGL(kern, grid, block, lds, stream, p);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ev.b, stream));
+    if (p.stack_ovf) HIPCHK(hipEventRecord(sc->ovf_done, stream));
     sc->pending.push_back({ev.a, ev.b});
     sc->primary_rays += (uint64_t)p.Hs * p.W * p.spp * n;
     return RT_OK;
@@ -455,7 +494,7 @@ RT_API size_t rt_tile_bytes(const rt_tile_request* rq) {
     return (size_t)(rq->height / rq->divisions) * rq->width * 3;   // main.rs:53-59
 }
 
-RT_API int rt_init(int* n_devices) {
+static int rt_init_impl(int* n_devices) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (g_init) {
         if (n_devices) *n_devices = (int)g_ctx.size();
@@ -502,8 +541,10 @@ static int ensure_ctx(DeviceCtx* c) {
     return RT_OK;
 }
 
-RT_API void rt_shutdown(void) {
+static int rt_shutdown_impl(void) {
     std::lock_guard<std::mutex> lk(g_mu);
+    if (g_live_scenes.load() > 0)
+        return fail(RT_ERR_BAD_ARG, "rt_shutdown() refused: destroy every rt_scene first (their device contexts stay valid)");
     for (DeviceCtx* c : g_ctx) {
         (void)hipSetDevice(c->dev);
         if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -512,34 +553,43 @@ RT_API void rt_shutdown(void) {
     }
     g_ctx.clear();
     g_init = false;
+    return RT_OK;
 }
 
-RT_API int rt_scene_create(int device, const rt_sphere* sp, uint32_t ns, const rt_triangle* tr, uint32_t nt,
-                           rt_scene** out) {
-    const auto t_create0 = std::chrono::steady_clock::now();
-    if (!out) return fail(RT_ERR_BAD_ARG, "out_scene is NULL");
-    *out = nullptr;
+static int rt_scene_destroy_impl(rt_scene* sc);
+
+// Everything rt_scene_create derives on the host from the primitive lists: the device-layout arrays and the reference's
+// candidate-filter BVH.  rt_render_frame builds it ONCE per job and uploads it to every device.
+struct HostScene {
+    uint32_t ns = 0, nt = 0, n_sph_pad = 0;
+    std::vector<float4> geom, geom_pk, geom_px, mat, tri_box, geom_r;
+    std::vector<float> emis, tri;
+    bool expanded = false, quant_ok = false;
+    float leaf_density = 0.f, bvh_build_ms = 0.f;
+    uint32_t n_internal = 0;         // internal nodes of the tree (bvh.trav may carry one placeholder)
+    rtbvh::FlatBVH bvh;
+};
+
+static int check_world(const rt_sphere* sp, uint32_t ns, const rt_triangle* tr, uint32_t nt) {
     if ((ns && !sp) || (nt && !tr)) return fail(RT_ERR_BAD_ARG, "primitive pointer is NULL");
-    if (!g_init) return fail(RT_ERR_NOT_INITIALIZED, "call rt_init() first");
-    if (device < 0 || device >= (int)g_ctx.size()) return fail(RT_ERR_BAD_DEVICE, "bad device ordinal");
-    if ((uint64_t)ns + nt > 0x7ffffff0ull) return fail(RT_ERR_LIMIT, "too many primitives");
-    DeviceCtx* ctx = g_ctx[device];
-    {
-        int rc0 = ensure_ctx(ctx);
-        if (rc0) return rc0;
-    }
-    HIPCHK(hipSetDevice(ctx->dev));
-    rt_scene* sc = new (std::nothrow) rt_scene;
-    if (!sc) return fail(RT_ERR_OOM, "host allocation failed");
-    sc->ctx = ctx;
-    sc->n_sph = ns;
-    sc->n_tri = nt;
-    sc->n_sph_pad = (ns + rtk::UNROLL - 1) / rtk::UNROLL * rtk::UNROLL;
+    // the kernels address nodes (64 B), geometry (16 B), materials (16 B) and triangles (36 B) with 32-bit byte offsets
+    if ((uint64_t)ns + nt > RT_MAX_PRIMITIVES) return fail(RT_ERR_LIMIT, "too many primitives (RT_MAX_PRIMITIVES)");
+    return RT_OK;
+}
+
+static void build_host_scene(const rt_sphere* sp, uint32_t ns, const rt_triangle* tr, uint32_t nt, HostScene& hs) {
+    hs.ns = ns;
+    hs.nt = nt;
+    hs.n_sph_pad = (ns + rtk::UNROLL - 1) / rtk::UNROLL * rtk::UNROLL;
     const uint32_t np = ns + nt;
-    std::vector<float4> geom(sc->n_sph_pad ? sc->n_sph_pad : 1);
-    std::vector<float4> mat(np ? np : 1);
-    std::vector<float> emis(np ? np : 1);
-    std::vector<float> tri((size_t)nt * 9 + 1);
+    std::vector<float4>& geom = hs.geom;
+    std::vector<float4>& mat = hs.mat;
+    std::vector<float>& emis = hs.emis;
+    std::vector<float>& tri = hs.tri;
+    geom.assign(hs.n_sph_pad ? hs.n_sph_pad : 1, make_float4(0.f, 0.f, 0.f, 0.f));
+    mat.assign(np ? np : 1, make_float4(0.f, 0.f, 0.f, 0.f));
+    emis.assign(np ? np : 1, 0.f);
+    tri.assign((size_t)nt * 9 + 1, 0.f);
     for (uint32_t i = 0; i < ns; i++) {
         // rr = radius.powi(2) (sphere.rs:45): one rounded multiply
         volatile float rr = sp[i].radius * sp[i].radius;
@@ -548,10 +598,11 @@ RT_API int rt_scene_create(int device, const rt_sphere* sp, uint32_t ns, const r
         emis[i] = sp[i].emission;
     }
     // padding spheres can never pass either phase: rr = -inf makes every discriminant -inf
-    for (uint32_t i = ns; i < sc->n_sph_pad; i++) geom[i] = make_float4(0.f, 0.f, 0.f, -INFINITY);
+    for (uint32_t i = ns; i < hs.n_sph_pad; i++) geom[i] = make_float4(0.f, 0.f, 0.f, -INFINITY);
     // pair layout for the packed-FP32 broad phase: (c0x,c1x,c0y,c1y) (c0z,c1z,rr0,rr1)
-    std::vector<float4> geom_pk(geom.size());
-    for (uint32_t i = 0; i + 1 < sc->n_sph_pad; i += 2) {
+    std::vector<float4>& geom_pk = hs.geom_pk;
+    geom_pk.assign(geom.size(), make_float4(0.f, 0.f, 0.f, 0.f));
+    for (uint32_t i = 0; i + 1 < hs.n_sph_pad; i += 2) {
         geom_pk[i] = make_float4(geom[i].x, geom[i + 1].x, geom[i].y, geom[i + 1].y);
         geom_pk[i + 1] = make_float4(geom[i].z, geom[i + 1].z, geom[i].w, geom[i + 1].w);
     }
@@ -562,12 +613,13 @@ RT_API int rt_scene_create(int device, const rt_sphere* sp, uint32_t ns, const r
     }
     // expanded-form broad phase records: w = |c|^2 - rr - 2^-16 (|c|^2 + rr), evaluated in
     // double and rounded DOWN to f32 (conservative).
-    std::vector<float4> geom_px(geom.size());
+    std::vector<float4>& geom_px = hs.geom_px;
+    geom_px.assign(geom.size(), make_float4(0.f, 0.f, 0.f, 0.f));
     {
         std::vector<float4> px(geom.size());
         std::vector<double> ratio;
         const double K = std::ldexp(1.0, -16);
-        for (uint32_t i = 0; i < sc->n_sph_pad; i++) {
+        for (uint32_t i = 0; i < hs.n_sph_pad; i++) {
             if (i >= ns) {
                 px[i] = make_float4(0.f, 0.f, 0.f, INFINITY);      // w = +inf: t = -inf, never a candidate
                 continue;
@@ -580,7 +632,7 @@ RT_API int rt_scene_create(int device, const rt_sphere* sp, uint32_t ns, const r
             px[i] = make_float4(sp[i].cx, sp[i].cy, sp[i].cz, wf);
             if (rr > 0) ratio.push_back(K * 2.0 * cc / rr);
         }
-        for (uint32_t i = 0; i + 1 < sc->n_sph_pad; i += 2) {
+        for (uint32_t i = 0; i + 1 < hs.n_sph_pad; i += 2) {
             geom_px[i] = make_float4(px[i].x, px[i + 1].x, px[i].y, px[i + 1].y);
             geom_px[i + 1] = make_float4(px[i].z, px[i + 1].z, px[i].w, px[i + 1].w);
         }
@@ -593,7 +645,7 @@ RT_API int rt_scene_create(int device, const rt_sphere* sp, uint32_t ns, const r
         }
         for (uint32_t i = 0; i < ns && ok; i++)
             ok = std::isfinite(px[i].x) && std::isfinite(px[i].y) && std::isfinite(px[i].z) && std::isfinite(px[i].w);
-        sc->expanded = ok;
+        hs.expanded = ok;
     }
     // the reference's candidate-filter BVH (slave main.rs:60), built once per scene instead of per strip
     std::vector<rtbvh::Box> boxes(np);
@@ -613,22 +665,20 @@ RT_API int rt_scene_create(int device, const rt_sphere* sp, uint32_t ns, const r
             boxes[ns + i].hi[a] = x1 > vb ? x1 : vb;
         }
     }
-    std::vector<float4> tri_box((size_t)nt * 2 + 1);
+    hs.tri_box.assign((size_t)nt * 2 + 1, make_float4(0.f, 0.f, 0.f, 0.f));
     for (uint32_t i = 0; i < nt; i++) {
         const rtbvh::Box& b = boxes[ns + i];
-        tri_box[2 * (size_t)i] = make_float4(b.lo[0], b.lo[1], b.lo[2], 0.f);
-        tri_box[2 * (size_t)i + 1] = make_float4(b.hi[0], b.hi[1], b.hi[2], 0.f);
+        hs.tri_box[2 * (size_t)i] = make_float4(b.lo[0], b.lo[1], b.lo[2], 0.f);
+        hs.tri_box[2 * (size_t)i + 1] = make_float4(b.hi[0], b.hi[1], b.hi[2], 0.f);
     }
     auto tb0 = std::chrono::steady_clock::now();
-    rtbvh::FlatBVH bvh = rtbvh::build(boxes);
-    sc->bvh_build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - tb0).count();
+    hs.bvh = rtbvh::build(boxes);
+    rtbvh::FlatBVH& bvh = hs.bvh;
+    hs.bvh_build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - tb0).count();
+    hs.n_internal = (uint32_t)bvh.trav.size();        // before the placeholders below
     if (bvh.nodes.empty()) bvh.nodes.push_back(rtbvh::FlatNode{{0, 0, 0}, 0xffffffffu, {0, 0, 0}, 0});
     if (bvh.leaf_of.empty()) bvh.leaf_of.push_back(0);
-    sc->root_ref = bvh.root_ref;
-    sc->bvh_depth = bvh.depth;
-    sc->n_internal = (uint32_t)bvh.trav.size();
     if (bvh.trav.empty()) bvh.trav.push_back(rtbvh::TravNode{});
-    sc->grid = bvh.grid;
     if (bvh.travq.empty()) bvh.travq.push_back(rtbvh::QNode{});
     {
         // worthwhile only if the grid step is small against the primitives (else the rounded boxes admit crowds of
@@ -645,7 +695,7 @@ RT_API int rt_scene_create(int device, const rt_sphere* sp, uint32_t ns, const r
             std::nth_element(edge.begin(), edge.begin() + np / 2, edge.end());
             ok = edge[np / 2] >= 8.0f;
         }
-        sc->quant_ok = ok;
+        hs.quant_ok = ok;
         // leaf density = sum of primitive box areas / area of the scene box ~ leaves a random ray reaches; above ~2
         // the walk is bound by the exact leaf tests, where the lighter exact-node kernel (5 waves/SIMD) wins
         double area = 0.0, root = 0.0;
@@ -663,78 +713,113 @@ RT_API int rt_scene_create(int device, const rt_sphere* sp, uint32_t ns, const r
             const double ex = (double)hi[0] - lo[0], ey = (double)hi[1] - lo[1], ez = (double)hi[2] - lo[2];
             root = ex * ey + ey * ez + ez * ex;
         }
-        sc->leaf_density = root > 0.0 ? (float)(area / root) : INFINITY;
+        hs.leaf_density = root > 0.0 ? (float)(area / root) : INFINITY;
     }
-    std::vector<float4> geom_r(ns ? ns : 1);
-    for (uint32_t i = 0; i < ns; i++) geom_r[i] = make_float4(sp[i].cx, sp[i].cy, sp[i].cz, sp[i].radius);
-    auto cleanup = [&](int code) {
-        rt_scene_destroy(sc);
-        return code;
-    };
+    hs.geom_r.assign(ns ? ns : 1, make_float4(0.f, 0.f, 0.f, 0.f));
+    for (uint32_t i = 0; i < ns; i++) hs.geom_r[i] = make_float4(sp[i].cx, sp[i].cy, sp[i].cz, sp[i].radius);
+}
+
+// HostScene -> device: allocate, upload on the device's stream, hand back the handle
+static int upload_scene(int device, const HostScene& hs, rt_scene** out) {
+    const auto t_create0 = std::chrono::steady_clock::now();
+    if (!g_init) return fail(RT_ERR_NOT_INITIALIZED, "call rt_init() first");
+    if (device < 0 || device >= (int)g_ctx.size()) return fail(RT_ERR_BAD_DEVICE, "bad device ordinal");
+    DeviceCtx* ctx = g_ctx[device];
+    {
+        int rc0 = ensure_ctx(ctx);
+        if (rc0) return rc0;
+    }
+    HIPCHK(hipSetDevice(ctx->dev));
+    rt_scene* sc = new (std::nothrow) rt_scene;
+    if (!sc) return fail(RT_ERR_OOM, "host allocation failed");
+    g_live_scenes.fetch_add(1);            // (rt_scene_destroy_impl, also on the error paths below, takes it back)
+    struct SceneGuard {                    // an error return or an exception below releases everything made so far
+        rt_scene* sc;
+        ~SceneGuard() {
+            if (sc) rt_scene_destroy_impl(sc);
+        }
+    } guard{sc};
+    const rtbvh::FlatBVH& bvh = hs.bvh;
+    sc->ctx = ctx;
+    sc->n_sph = hs.ns;
+    sc->n_tri = hs.nt;
+    sc->n_sph_pad = hs.n_sph_pad;
+    sc->expanded = hs.expanded;
+    sc->bvh_build_ms = hs.bvh_build_ms;
+    sc->root_ref = bvh.root_ref;
+    sc->bvh_depth = bvh.depth;
+    sc->n_internal = hs.n_internal;
+    sc->grid = bvh.grid;
+    sc->quant_ok = hs.quant_ok;
+    sc->leaf_density = hs.leaf_density;
     hipEvent_t e0, e1;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
-        return cleanup(fail(RT_ERR_HIP, "hipEventCreate failed"));
+    if (hipEventCreate(&e0) != hipSuccess) return fail(RT_ERR_HIP, "hipEventCreate failed");
+    if (hipEventCreate(&e1) != hipSuccess) {
+        (void)hipEventDestroy(e0);
+        return fail(RT_ERR_HIP, "hipEventCreate failed");
+    }
 #define SC_CHK(expr)                                                                      \
     do {                                                                                  \
         hipError_t _e = (expr);                                                           \
         if (_e != hipSuccess) {                                                           \
             (void)hipEventDestroy(e0);                                                    \
             (void)hipEventDestroy(e1);                                                    \
-            return cleanup(fail(_e == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_HIP,      \
-                                std::string(#expr) + ": " + hipGetErrorString(_e)));      \
+            return fail(_e == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_HIP,              \
+                        std::string(#expr) + ": " + hipGetErrorString(_e));               \
         }                                                                                 \
     } while (0)
-    SC_CHK(hipMalloc(&sc->d_geom, geom.size() * sizeof(float4)));
-    SC_CHK(hipMalloc(&sc->d_geom_pk, geom_pk.size() * sizeof(float4)));
-    SC_CHK(hipMalloc(&sc->d_geom_px, geom_px.size() * sizeof(float4)));
-    SC_CHK(hipMalloc(&sc->d_mat, mat.size() * sizeof(float4)));
-    SC_CHK(hipMalloc(&sc->d_emis, emis.size() * sizeof(float)));
-    SC_CHK(hipMalloc(&sc->d_tri, tri.size() * sizeof(float)));
-    SC_CHK(hipMalloc(&sc->d_tri_box, tri_box.size() * sizeof(float4)));
-    SC_CHK(hipMalloc(&sc->d_bvh, bvh.nodes.size() * sizeof(rtbvh::FlatNode)));
-    SC_CHK(hipMalloc(&sc->d_leaf_of, bvh.leaf_of.size() * sizeof(uint32_t)));
-    SC_CHK(hipMalloc(&sc->d_trav, bvh.trav.size() * sizeof(rtbvh::TravNode)));
-    SC_CHK(hipMalloc(&sc->d_travq, bvh.travq.size() * sizeof(rtbvh::QNode)));
-    SC_CHK(hipMalloc(&sc->d_geom_r, geom_r.size() * sizeof(float4)));
-    SC_CHK(hipMalloc(&sc->d_counters, COUNTER_WORDS * sizeof(unsigned long long)));
+#define SC_UP(dst, vec)                                                                                       \
+    do {                                                                                                      \
+        SC_CHK(hipMalloc(&sc->dst, (vec).size() * sizeof((vec)[0])));                                         \
+        SC_CHK(hipMemcpyAsync(sc->dst, (vec).data(), (vec).size() * sizeof((vec)[0]), hipMemcpyHostToDevice,  \
+                              ctx->stream));                                                                  \
+    } while (0)
     SC_CHK(hipEventRecord(e0, ctx->stream));
-    SC_CHK(hipMemcpyAsync(sc->d_geom, geom.data(), geom.size() * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
-    SC_CHK(hipMemcpyAsync(sc->d_geom_pk, geom_pk.data(), geom_pk.size() * sizeof(float4), hipMemcpyHostToDevice,
-                          ctx->stream));
-    SC_CHK(hipMemcpyAsync(sc->d_geom_px, geom_px.data(), geom_px.size() * sizeof(float4), hipMemcpyHostToDevice,
-                          ctx->stream));
-    SC_CHK(hipMemcpyAsync(sc->d_mat, mat.data(), mat.size() * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
-    SC_CHK(hipMemcpyAsync(sc->d_emis, emis.data(), emis.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    SC_CHK(hipMemcpyAsync(sc->d_tri, tri.data(), tri.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    SC_CHK(hipMemcpyAsync(sc->d_tri_box, tri_box.data(), tri_box.size() * sizeof(float4), hipMemcpyHostToDevice,
-                          ctx->stream));
-    SC_CHK(hipMemcpyAsync(sc->d_bvh, bvh.nodes.data(), bvh.nodes.size() * sizeof(rtbvh::FlatNode), hipMemcpyHostToDevice,
-                          ctx->stream));
-    SC_CHK(hipMemcpyAsync(sc->d_travq, bvh.travq.data(), bvh.travq.size() * sizeof(rtbvh::QNode), hipMemcpyHostToDevice,
-                          ctx->stream));
-    SC_CHK(hipMemcpyAsync(sc->d_geom_r, geom_r.data(), geom_r.size() * sizeof(float4), hipMemcpyHostToDevice,
-                          ctx->stream));
-    SC_CHK(hipMemcpyAsync(sc->d_trav, bvh.trav.data(), bvh.trav.size() * sizeof(rtbvh::TravNode), hipMemcpyHostToDevice,
-                          ctx->stream));
-    SC_CHK(hipMemcpyAsync(sc->d_leaf_of, bvh.leaf_of.data(), bvh.leaf_of.size() * sizeof(uint32_t),
-                          hipMemcpyHostToDevice, ctx->stream));
+    SC_UP(d_geom, hs.geom);
+    SC_UP(d_geom_pk, hs.geom_pk);
+    SC_UP(d_geom_px, hs.geom_px);
+    SC_UP(d_mat, hs.mat);
+    SC_UP(d_emis, hs.emis);
+    SC_UP(d_tri, hs.tri);
+    SC_UP(d_tri_box, hs.tri_box);
+    SC_UP(d_bvh, bvh.nodes);
+    SC_UP(d_leaf_of, bvh.leaf_of);
+    SC_UP(d_trav, bvh.trav);
+    SC_UP(d_travq, bvh.travq);
+    SC_UP(d_geom_r, hs.geom_r);
+    SC_CHK(hipMalloc(&sc->d_counters, COUNTER_WORDS * sizeof(unsigned long long)));
     SC_CHK(hipMemsetAsync(sc->d_counters, 0, COUNTER_WORDS * sizeof(unsigned long long), ctx->stream));
     SC_CHK(hipEventRecord(e1, ctx->stream));
     SC_CHK(hipEventSynchronize(e1));
     SC_CHK(hipEventElapsedTime(&sc->h2d_ms, e0, e1));
+#undef SC_UP
 #undef SC_CHK
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     if (getenv("RT_VERBOSE"))
-        fprintf(stderr, "[rt] scene: %u prims  bvh build %.2f ms (host)  uploads %.2f ms  total %.2f ms\n", np,
-                sc->bvh_build_ms, sc->h2d_ms,
+        fprintf(stderr, "[rt] scene: %u prims  bvh build %.2f ms (host)  uploads %.2f ms  upload total %.2f ms\n",
+                hs.ns + hs.nt, sc->bvh_build_ms, sc->h2d_ms,
                 std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_create0).count());
+    guard.sc = nullptr;
     *out = sc;
     return RT_OK;
 }
 
-RT_API void rt_scene_destroy(rt_scene* sc) {
-    if (!sc) return;
+static int rt_scene_create_impl(int device, const rt_sphere* sp, uint32_t ns, const rt_triangle* tr, uint32_t nt,
+                                rt_scene** out) {
+    if (!out) return fail(RT_ERR_BAD_ARG, "out_scene is NULL");
+    *out = nullptr;
+    int rc = check_world(sp, ns, tr, nt);
+    if (rc) return rc;
+    if (!g_init) return fail(RT_ERR_NOT_INITIALIZED, "call rt_init() first");
+    if (device < 0 || device >= (int)g_ctx.size()) return fail(RT_ERR_BAD_DEVICE, "bad device ordinal");
+    HostScene hs;
+    build_host_scene(sp, ns, tr, nt, hs);
+    return upload_scene(device, hs, out);
+}
+
+static int rt_scene_destroy_impl(rt_scene* sc) {
+    if (!sc) return RT_OK;
     if (sc->ctx) (void)hipSetDevice(sc->ctx->dev);
     for (auto& pr : sc->pending) {
         (void)hipEventSynchronize(pr.second);
@@ -756,12 +841,15 @@ RT_API void rt_scene_destroy(rt_scene* sc) {
     (void)hipFree(sc->d_trav);
     (void)hipFree(sc->d_travq);
     (void)hipFree(sc->d_stack_ovf);
+    if (sc->ovf_done) (void)hipEventDestroy(sc->ovf_done);
     (void)hipFree(sc->d_geom_r);
     (void)hipFree(sc->d_leaf_of);
     (void)hipFree(sc->d_counters);
     (void)hipFree(sc->d_out);
     (void)hipFree(sc->d_outf);
     delete sc;
+    g_live_scenes.fetch_sub(1);
+    return RT_OK;
 }
 
 static int check_batch(const rt_tile_request* rqs, uint32_t n) {
@@ -775,7 +863,7 @@ static int check_batch(const rt_tile_request* rqs, uint32_t n) {
     return RT_OK;
 }
 
-RT_API int rt_scene_render_tiles_device(rt_scene* sc, const rt_tile_request* rqs, uint32_t n,
+static int rt_scene_render_tiles_device_impl(rt_scene* sc, const rt_tile_request* rqs, uint32_t n,
                                         void* const* d_out_rgb, size_t out_len_each, void* const* d_out_f32,
                                         void* hip_stream) {
     if (!sc) return fail(RT_ERR_BAD_ARG, "scene is NULL");
@@ -796,21 +884,21 @@ RT_API int rt_scene_render_tiles_device(rt_scene* sc, const rt_tile_request* rqs
     return RT_OK;
 }
 
-RT_API int rt_scene_render_tile_device(rt_scene* sc, const rt_tile_request* rq, void* d_out_rgb, size_t out_len,
+static int rt_scene_render_tile_device_impl(rt_scene* sc, const rt_tile_request* rq, void* d_out_rgb, size_t out_len,
                                        void* d_out_f32, void* hip_stream) {
     void* rgb[1] = {d_out_rgb};
     void* f32[1] = {d_out_f32};
-    return rt_scene_render_tiles_device(sc, rq, 1, rgb, out_len, d_out_f32 ? f32 : nullptr, hip_stream);
+    return rt_scene_render_tiles_device_impl(sc, rq, 1, rgb, out_len, d_out_f32 ? f32 : nullptr, hip_stream);
 }
 
-RT_API int rt_scene_collect(rt_scene* sc, rt_tile_stats* st) {
+static int rt_scene_collect_impl(rt_scene* sc, rt_tile_stats* st) {
     if (!sc) return fail(RT_ERR_BAD_ARG, "scene is NULL");
     std::lock_guard<std::mutex> lk(sc->mu);
     HIPCHK(hipSetDevice(sc->ctx->dev));
     return collect_locked(sc, st);
 }
 
-RT_API int rt_scene_render_tiles(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, uint8_t* const* out_rgb,
+static int rt_scene_render_tiles_impl(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, uint8_t* const* out_rgb,
                                  size_t out_len_each, float* const* out_f32, rt_tile_stats* stats) {
     if (!sc) return fail(RT_ERR_BAD_ARG, "scene is NULL");
     int rc = check_batch(rqs, n);
@@ -864,10 +952,28 @@ RT_API int rt_scene_render_tiles(rt_scene* sc, const rt_tile_request* rqs, uint3
             groups.emplace_back(i0, std::min<uint32_t>(rtk::MAX_BATCH, n - i0));
     }
     hipStream_t cs = sc->ctx->copy_stream;
-    std::vector<EvPair> gev(groups.size());
+    std::vector<EvPair> gev;
+    gev.reserve(groups.size());
+    // whatever happens below, the events go back to the scene's free list, and an error return waits for the work
+    // already enqueued (it writes into caller memory)
+    struct EvReturn {
+        rt_scene* sc;
+        std::vector<EvPair>& v;
+        hipStream_t a, b;
+        bool ok = false;
+        ~EvReturn() {
+            if (!ok) {
+                (void)hipStreamSynchronize(a);
+                (void)hipStreamSynchronize(b);
+            }
+            for (auto& e : v) sc->free_ev.push_back({e.a, e.b});
+        }
+    } ev_return{sc, gev, st, cs};
     for (size_t g = 0; g < groups.size(); g++) {
-        rc = get_events(sc, gev[g]);
+        EvPair e;
+        rc = get_events(sc, e);
         if (rc) return rc;
+        gev.push_back(e);
     }
     for (size_t g = 0; g < groups.size(); g++) {
         const uint32_t i0 = groups[g].first, m = groups[g].second;
@@ -886,7 +992,7 @@ RT_API int rt_scene_render_tiles(rt_scene* sc, const rt_tile_request* rqs, uint3
     HIPCHK(hipEventSynchronize(gev.back().b));
     float d2h = 0.f;
     HIPCHK(hipEventElapsedTime(&d2h, gev.back().a, gev.back().b));   // last launch done -> last byte on the host
-    for (auto& e : gev) sc->free_ev.push_back({e.a, e.b});
+    ev_return.ok = true;
     rt_tile_stats s;
     rc = collect_locked(sc, &s);
     if (rc) return rc;
@@ -895,11 +1001,11 @@ RT_API int rt_scene_render_tiles(rt_scene* sc, const rt_tile_request* rqs, uint3
     return RT_OK;
 }
 
-RT_API int rt_scene_render_tile(rt_scene* sc, const rt_tile_request* rq, uint8_t* out_rgb, size_t out_len,
+static int rt_scene_render_tile_impl(rt_scene* sc, const rt_tile_request* rq, uint8_t* out_rgb, size_t out_len,
                                 float* out_f32, rt_tile_stats* stats) {
     uint8_t* rgb[1] = {out_rgb};
     float* f32[1] = {out_f32};
-    return rt_scene_render_tiles(sc, rq, 1, rgb, out_len, out_f32 ? f32 : nullptr, stats);
+    return rt_scene_render_tiles_impl(sc, rq, 1, rgb, out_len, out_f32 ? f32 : nullptr, stats);
 }
 
 // debug: raw read of the scene's device counter words (tools/phase_census.py); not part of rt_tile.h
@@ -912,7 +1018,7 @@ extern "C" __attribute__((visibility("default"))) int rt_debug_read_counters(rt_
     return RT_OK;
 }
 
-RT_API int rt_render_tile(int device, const rt_tile_request* rq, const rt_sphere* sp, uint32_t ns,
+static int rt_render_tile_impl(int device, const rt_tile_request* rq, const rt_sphere* sp, uint32_t ns,
                           const rt_triangle* tr, uint32_t nt, uint8_t* out_rgb, size_t out_len, float* out_f32,
                           rt_tile_stats* stats) {
     int rc = check_request(rq);
@@ -920,24 +1026,26 @@ RT_API int rt_render_tile(int device, const rt_tile_request* rq, const rt_sphere
     if (!out_rgb) return fail(RT_ERR_BAD_ARG, "out_rgb is NULL");
     if (out_len < rt_tile_bytes(rq)) return fail(RT_ERR_BUFFER_TOO_SMALL, "out_len < (H/div)*W*3");
     rt_scene* sc = nullptr;
-    rc = rt_scene_create(device, sp, ns, tr, nt, &sc);
+    rc = rt_scene_create_impl(device, sp, ns, tr, nt, &sc);
     if (rc) return rc;
-    rc = rt_scene_render_tile(sc, rq, out_rgb, out_len, out_f32, stats);
+    rc = rt_scene_render_tile_impl(sc, rq, out_rgb, out_len, out_f32, stats);
     std::string keep = g_err;
-    rt_scene_destroy(sc);
+    rt_scene_destroy_impl(sc);
     if (rc) g_err = keep;
     return rc;
 }
 
-RT_API int rt_render_frame(const int* devices, int n_devices, const rt_tile_request* rq_in, const rt_sphere* sp,
-                           uint32_t ns, const rt_triangle* tr, uint32_t nt, uint8_t* out_rgb, size_t out_len,
-                           rt_tile_stats* stats) {
+static int rt_render_frame_impl(const int* devices, int n_devices, const rt_tile_request* rq_in, const rt_sphere* sp,
+                                uint32_t ns, const rt_triangle* tr, uint32_t nt, uint8_t* out_rgb, size_t out_len,
+                                rt_tile_stats* stats) {
     if (!rq_in) return fail(RT_ERR_BAD_ARG, "request is NULL");
     rt_tile_request rq0 = *rq_in;
     rq0.division_no = 0;
     int rc = check_request(&rq0);
     if (rc) return rc;
     if (!out_rgb) return fail(RT_ERR_BAD_ARG, "out_rgb is NULL");
+    rc = check_world(sp, ns, tr, nt);
+    if (rc) return rc;
     if (!g_init) return fail(RT_ERR_NOT_INITIALIZED, "call rt_init() first");
     // the controller's ImageBuffer::from_vec(width, height, ..).unwrap() (controller main.rs:117-119)
     // panics unless the strips tile the frame exactly
@@ -952,42 +1060,118 @@ RT_API int rt_render_frame(const int* devices, int n_devices, const rt_tile_requ
     for (int d : devs)
         if (d < 0 || d >= (int)g_ctx.size()) return fail(RT_ERR_BAD_DEVICE, "bad device ordinal");
     const int nd = (int)devs.size();
+    // the world's host side once per job (the reference rebuilds the BVH per strip, slave main.rs:60)
+    HostScene hs;
+    build_host_scene(sp, ns, tr, nt, hs);
+    // page-lock the frame buffer for the call: strip downloads become DMA that runs under the kernels.  Best effort:
+    // a buffer the caller already registered (or that cannot be registered) is used as it is.
+    bool pinned = false;
+    {
+        const char* e = getenv("RT_PIN_FRAME");            // (read per call: tests and A/B runs flip it)
+        const bool pin = !e || atoi(e) != 0;
+        if (pin && hipHostRegister(out_rgb, strip * rq0.divisions, hipHostRegisterPortable) == hipSuccess) pinned = true;
+        else (void)hipGetLastError();
+    }
+    struct Unpin {
+        void* ptr;
+        bool on;
+        ~Unpin() {
+            if (on) (void)hipHostUnregister(ptr);
+        }
+    } unpin{out_rgb, pinned};
+    const bool use_queue = [] { const char* e = getenv("RT_FRAME_QUEUE"); return e && atoi(e) != 0; }();
+    std::atomic<uint32_t> next_strip{0};                  // RT_FRAME_QUEUE: strips handed out bottom-up
     std::vector<int> rcs(nd, RT_OK);
     std::vector<std::string> errs(nd);
     std::vector<rt_tile_stats> sts(nd);
-    // one host thread + one stream per device; strip k -> devs[k % nd]  (controller main.rs:47-75
-    // fires one request per division; Docker DNS round-robins them over the slaves)
-    auto work = [&](int w) {
-        std::memset(&sts[w], 0, sizeof(rt_tile_stats));
+    for (auto& st : sts) std::memset(&st, 0, sizeof st);
+    auto work = [&](int w) -> int {
         rt_scene* sc = nullptr;
-        int r = rt_scene_create(devs[w], sp, ns, tr, nt, &sc);   // world uploaded once per device per job
-        if (r) {
-            rcs[w] = r;
-            errs[w] = g_err;
-            return;
-        }
-        // all strips owned by this device go out as one batch (one launch per <= MAX_BATCH strips);
-        // stitch by division_no: strip k lands at byte offset k * strip (controller main.rs:109-115)
-        std::vector<rt_tile_request> rqs;
-        std::vector<uint8_t*> outs;
-        for (uint32_t k = (uint32_t)w; k < rq0.divisions; k += (uint32_t)nd) {
-            rt_tile_request rq = rq0;
-            rq.division_no = k;
-            rqs.push_back(rq);
-            outs.push_back(out_rgb + (size_t)k * strip);
-        }
-        if (!rqs.empty()) {
-            r = rt_scene_render_tiles(sc, rqs.data(), (uint32_t)rqs.size(), outs.data(), strip, nullptr, &sts[w]);
-            if (r) {
-                rcs[w] = r;
-                errs[w] = g_err;
+        int r = upload_scene(devs[w], hs, &sc);           // world uploaded once per device per job
+        if (r) return r;
+        struct Destroy {
+            rt_scene* sc;
+            ~Destroy() { rt_scene_destroy_impl(sc); }
+        } destroy{sc};
+        if (!use_queue) {
+            // strip k -> devs[k % nd] (controller main.rs:47-75 fires one request per division; Docker DNS round-robins
+            // them over the slaves): all strips of this device go out as one batch (one launch per <= MAX_BATCH strips);
+            // stitch by division_no: strip k lands at byte offset k * strip (controller main.rs:109-115)
+            std::vector<rt_tile_request> rqs;
+            std::vector<uint8_t*> outs;
+            for (uint32_t k = (uint32_t)w; k < rq0.divisions; k += (uint32_t)nd) {
+                rt_tile_request rq = rq0;
+                rq.division_no = k;
+                rqs.push_back(rq);
+                outs.push_back(out_rgb + (size_t)k * strip);
             }
+            if (rqs.empty()) return RT_OK;
+            return rt_scene_render_tiles_impl(sc, rqs.data(), (uint32_t)rqs.size(), outs.data(), strip, nullptr, &sts[w]);
         }
-        rt_scene_destroy(sc);
+        // ---- dynamic assignment: pull one strip at a time, the bottom of the frame first (its strips cost the most:
+        // longest-first keeps the devices' finish times within one cheap strip of each other).  Two strips in flight per
+        // device, each on its own stream with its own device buffer: the launch tail and the download of one run under
+        // the other.
+        DeviceCtx* ctx = sc->ctx;
+        HIPCHK(hipSetDevice(ctx->dev));
+        struct Slot {
+            hipStream_t st = nullptr;
+            uint8_t* d = nullptr;
+            bool busy = false;
+            ~Slot() {
+                if (st) {
+                    (void)hipStreamSynchronize(st);
+                    (void)hipStreamDestroy(st);
+                }
+                (void)hipFree(d);
+            }
+        } slot[2];
+        for (auto& sl : slot) {
+            HIPCHK(hipStreamCreateWithFlags(&sl.st, hipStreamNonBlocking));
+            if (hipMalloc(&sl.d, strip) != hipSuccess) return fail(RT_ERR_OOM, "hipMalloc(strip) failed");
+        }
+        for (uint32_t turn = 0;; turn++) {
+            Slot& sl = slot[turn & 1];
+            if (sl.busy) {
+                HIPCHK(hipStreamSynchronize(sl.st));
+                sl.busy = false;
+            }
+            const uint32_t i = next_strip.fetch_add(1);
+            if (i >= rq0.divisions) break;
+            rt_tile_request rq = rq0;
+            rq.division_no = rq0.divisions - 1u - i;
+            void* d1[1] = {sl.d};
+            r = rt_scene_render_tiles_device_impl(sc, &rq, 1, d1, strip, nullptr, sl.st);
+            if (r) return r;
+            HIPCHK(hipMemcpyAsync(out_rgb + (size_t)rq.division_no * strip, sl.d, strip, hipMemcpyDeviceToHost, sl.st));
+            sl.busy = true;
+        }
+        for (auto& sl : slot)
+            if (sl.busy) HIPCHK(hipStreamSynchronize(sl.st));
+        return rt_scene_collect_impl(sc, &sts[w]);
     };
-    std::vector<std::thread> th;
-    for (int w = 0; w < nd; w++) th.emplace_back(work, w);
-    for (auto& t : th) t.join();
+    {
+        std::vector<std::thread> th;
+        struct Join {
+            std::vector<std::thread>& th;
+            ~Join() {
+                for (auto& t : th)
+                    if (t.joinable()) t.join();
+            }
+        } join{th};
+        th.reserve(nd);
+        // an exception must not leave a thread function either (std::terminate): same guard as the entry points
+        for (int w = 0; w < nd; w++)
+            th.emplace_back([&, w] {
+                rcs[w] = guarded([&] { return work(w); });
+                if (rcs[w]) {
+                    try {
+                        errs[w] = g_err;
+                    } catch (...) {
+                    }
+                }
+            });
+    }
     rt_tile_stats tot;
     std::memset(&tot, 0, sizeof tot);
     for (int w = 0; w < nd; w++) {
@@ -1006,6 +1190,49 @@ RT_API int rt_render_frame(const int* devices, int n_devices, const rt_tile_requ
     }
     if (stats) *stats = tot;
     return RT_OK;
+}
+
+// ---- the exported entry points: argument-for-argument the functions above, behind guarded() ----------------------
+RT_API int rt_init(int* n_devices) { return guarded([&] { return rt_init_impl(n_devices); }); }
+RT_API void rt_shutdown(void) { (void)guarded([&] { return rt_shutdown_impl(); }); }
+RT_API int rt_scene_create(int device, const rt_sphere* sp, uint32_t ns, const rt_triangle* tr, uint32_t nt, rt_scene** out) {
+    return guarded([&] { return rt_scene_create_impl(device, sp, ns, tr, nt, out); });
+}
+RT_API void rt_scene_destroy(rt_scene* sc) { (void)guarded([&] { return rt_scene_destroy_impl(sc); }); }
+RT_API int rt_scene_render_tiles_device(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* const* d_out_rgb,
+                                        size_t out_len_each, void* const* d_out_f32, void* hip_stream) {
+    return guarded([&] { return rt_scene_render_tiles_device_impl(sc, rqs, n, d_out_rgb, out_len_each, d_out_f32, hip_stream); });
+}
+RT_API int rt_scene_render_tile_device(rt_scene* sc, const rt_tile_request* rq, void* d_out_rgb, size_t out_len,
+                                       void* d_out_f32, void* hip_stream) {
+    return guarded([&] { return rt_scene_render_tile_device_impl(sc, rq, d_out_rgb, out_len, d_out_f32, hip_stream); });
+}
+RT_API int rt_scene_collect(rt_scene* sc, rt_tile_stats* st) { return guarded([&] { return rt_scene_collect_impl(sc, st); }); }
+RT_API int rt_scene_render_tiles(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, uint8_t* const* out_rgb,
+                                 size_t out_len_each, float* const* out_f32, rt_tile_stats* stats) {
+    return guarded([&] { return rt_scene_render_tiles_impl(sc, rqs, n, out_rgb, out_len_each, out_f32, stats); });
+}
+RT_API int rt_scene_render_tile(rt_scene* sc, const rt_tile_request* rq, uint8_t* out_rgb, size_t out_len, float* out_f32,
+                                rt_tile_stats* stats) {
+    return guarded([&] { return rt_scene_render_tile_impl(sc, rq, out_rgb, out_len, out_f32, stats); });
+}
+RT_API int rt_render_tile(int device, const rt_tile_request* rq, const rt_sphere* sp, uint32_t ns, const rt_triangle* tr,
+                          uint32_t nt, uint8_t* out_rgb, size_t out_len, float* out_f32, rt_tile_stats* stats) {
+    return guarded([&] { return rt_render_tile_impl(device, rq, sp, ns, tr, nt, out_rgb, out_len, out_f32, stats); });
+}
+RT_API int rt_render_frame(const int* devices, int n_devices, const rt_tile_request* rq, const rt_sphere* sp, uint32_t ns,
+                           const rt_triangle* tr, uint32_t nt, uint8_t* out_rgb, size_t out_len, rt_tile_stats* stats) {
+    return guarded([&] { return rt_render_frame_impl(devices, n_devices, rq, sp, ns, tr, nt, out_rgb, out_len, stats); });
+}
+// test hook (tests/test_abi.py, not part of rt_tile.h): throw inside a guarded body; the status comes back, nothing unwinds
+extern "C" __attribute__((visibility("default"))) int rt_debug_throw(int kind) {
+    return guarded([&]() -> int {
+        if (kind == 0) throw std::bad_alloc();
+        if (kind == 1) throw std::runtime_error("rt_debug_throw");
+        if (kind == 2) throw 42;
+        if (kind == 3) { std::vector<char> v; v.reserve((size_t)-1 / 2); }      // a real failed allocation (length_error / bad_alloc)
+        return RT_OK;
+    });
 }
 
 }  // extern "C"

@@ -62,13 +62,17 @@ constexpr int TRAV_STACK = 64;   // traversal stack entries per lane (host falls
 #ifndef RT_STEPS_PER_CHECK
 #define RT_STEPS_PER_CHECK 8
 #endif
+#ifndef RT_STEPS_PER_CHECK_LTREE   // LDS-tree kernel: steps per block of its branch-free walk (tools/sweep_steps.sh: 6 at refill 1/8)
+#define RT_STEPS_PER_CHECK_LTREE 6
+#endif
 #ifndef RT_STEPS_PER_CHECK_Q    // quantised-node kernel (large scenes, long walks): c5 +1 % over 8
 #define RT_STEPS_PER_CHECK_Q 16
 #endif
 constexpr int MAXL = RT_MAXL;    // leaf-candidate slots per lane in traversal mode (flushed when full)
 constexpr int MINL = RT_MINL;
 constexpr int MAXL_EXACT = 7;     // exact-node kernel: fixed (see the kernel)
-constexpr int LNODE_DW = 20;      // LDS-tree kernel: dwords per staged node (see the staging code)
+constexpr int LNODE_DW = 21;      // LDS-tree kernel: dwords per staged node (see the staging code); odd, so that the
+                                  // nodes start on all 32 banks
 constexpr int MAXL_LTREE = 12;    // LDS-tree kernel (16-bit entries): a block of RT_STEPS_PER_CHECK appends always fits
 constexpr uint32_t LEAF_BIT = 0x80000000u;
 
@@ -494,6 +498,11 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 3 ? R
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
+    // Column of this lane in the per-lane arrays of 16-bit entries ([slot][BLOCK]): lanes 0-31 of a wave take the low
+    // halves of 32 consecutive dwords, lanes 32-63 the high halves, so the 32 lanes the LDS serves together touch 32
+    // different banks whatever their slots (with column = tid, lanes 2k and 2k+1 shared a bank: 2-way conflicts
+    // whenever neighbours differed in stack depth)
+    const int tid16 = (tid & ~63) | ((tid & 31) << 1) | ((tid >> 5) & 1);
 
     if (ISECT == 0) {
         // resident scene: stage the whole primitive list into LDS once
@@ -504,18 +513,18 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 3 ? R
     }
 
     if (LTREE) {
-        // Stage the whole tree once per workgroup, 80 bytes per node, laid out for SIGN-SELECTED plane fetches: for
+        // Stage the whole tree once per workgroup, 84 bytes per node, laid out for SIGN-SELECTED plane fetches: for
         // each axis and child the three dwords (lo, hi, lo), so that a two-dword read at dword offset s = (d.axis < 0)
         // returns (near, far) = (aabb[sign], aabb[1 - sign]) — literally ray.rs:175-176 — with no min / max / select in
         // the step.  Dwords: l.x 0-2, r.x 3-5, l.y 6-8, r.y 9-11, l.z 12-14, r.z 15-17, 18 = left | right << 16 (16-bit
-        // references, leaf flag 0x8000).  Entry n_internal is node DONE: NaN planes, entered by no ray.
+        // references, leaf flag 0x8000; a node reference is the node's offset in dwords).  Entry n_internal is node DONE: NaN planes.
         float* ln = reinterpret_cast<float*>(lds_raw + p.lds_node_off);
         for (uint32_t n = tid; n <= p.n_internal; n += BLOCK) {
             float* q = ln + LNODE_DW * n;
             if (n < p.n_internal) {
                 const float4 a0 = p.trav[4u * n], a1 = p.trav[4u * n + 1], a2 = p.trav[4u * n + 2], a3 = p.trav[4u * n + 3];
-                // a child reference is 0x8000 | primitive, or the child node's offset in 16-byte units (= 5 * index)
-                auto ref16 = [](uint32_t r) { return (r & LEAF_BIT) ? (0x8000u | (r & 0x7fffu)) : r * (uint32_t)(LNODE_DW / 4); };
+                // a child reference is 0x8000 | primitive, or the child node's offset in dwords (= LNODE_DW * index)
+                auto ref16 = [](uint32_t r) { return (r & LEAF_BIT) ? (0x8000u | (r & 0x7fffu)) : r * (uint32_t)LNODE_DW; };
                 q[0] = a0.x; q[1] = a1.x; q[2] = a0.x;   q[3] = a2.x; q[4] = a3.x; q[5] = a2.x;
                 q[6] = a0.y; q[7] = a1.y; q[8] = a0.y;   q[9] = a2.y; q[10] = a3.y; q[11] = a2.y;
                 q[12] = a0.z; q[13] = a1.z; q[14] = a0.z; q[15] = a2.z; q[16] = a3.z; q[17] = a2.z;
@@ -523,9 +532,10 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 3 ? R
             } else {
                 const float qn = __builtin_nanf("");
                 for (int i = 0; i < 18; i++) q[i] = qn;
-                q[18] = __uint_as_float((p.n_internal * (uint32_t)(LNODE_DW / 4)) * 0x10001u);
+                q[18] = __uint_as_float((p.n_internal * (uint32_t)LNODE_DW) * 0x10001u);
             }
             q[19] = 0.f;
+            q[20] = 0.f;
         }
         const uint32_t np = p.n_sph + p.n_tri;
         if (p.lds_mat_off != 0xffffffffu) {
@@ -604,7 +614,7 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 3 ? R
     uint16_t* lc16 = reinterpret_cast<uint16_t*>(lds_raw + p.lds_cand_off);     // LTREE: both 16-bit
     uint16_t* lstack16 = reinterpret_cast<uint16_t*>(lds_raw + p.lds_stack_off);
 
-    if (BFSTEP) lstack16[tid] = (uint16_t)(p.n_internal * (uint32_t)(LNODE_DW / 4));  // stack slot 0: popping an empty stack yields DONE
+    if (BFSTEP) lstack16[tid16] = (uint16_t)(p.n_internal * (uint32_t)LNODE_DW);  // stack slot 0: popping an empty stack yields DONE
 
     auto drain_counters = [&]() {
         const unsigned long long ws = wave_sum(n_seg), wc = wave_sum(n_cand), wf = wave_sum(n_fall);
@@ -777,7 +787,7 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 3 ? R
 #pragma clang loop unroll(disable)
                 for (uint32_t i = 0; i < t_cnt; i++) {
                     LCOUNT(6);
-                    const uint32_t prim = LTREE ? (uint32_t)lc16[i * BLOCK + tid] & 0x7fffu : lc32[i * BLOCK + tid];
+                    const uint32_t prim = LTREE ? (uint32_t)lc16[i * BLOCK + tid16] & 0x7fffu : lc32[i * BLOCK + tid];
                     float t;
                     // The quantised walk only over-approximates BVH::traverse, so a leaf it delivers counts iff
                     // the reference would have reached it = its own exact box passes (leaf-box lemma, bvh_reaches;
@@ -813,14 +823,14 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 3 ? R
             // kernel (large scenes, deep trees) keeps p.stack_lds entries there and the rare deeper ones in HBM, so
             // that the tree's depth does not take the CU's LDS away from its occupancy.
             auto push = [&](uint32_t v) {
-                if (LTREE) lstack16[t_sp * BLOCK + tid] = (uint16_t)v;
+                if (LTREE) lstack16[t_sp * BLOCK + tid16] = (uint16_t)v;
                 else if (!CAPPED || t_sp < p.stack_lds) lstack[t_sp * BLOCK + tid] = v;
                 else p.stack_ovf[(size_t)(t_sp - p.stack_lds) * p.ovf_stride + (blockIdx.x * BLOCK + tid)] = v;
                 t_sp++;
             };
             auto pop = [&]() -> uint32_t {
                 --t_sp;
-                if (LTREE) return (uint32_t)lstack16[t_sp * BLOCK + tid];
+                if (LTREE) return (uint32_t)lstack16[t_sp * BLOCK + tid16];
                 if (!CAPPED || t_sp < p.stack_lds) return lstack[t_sp * BLOCK + tid];
                 return p.stack_ovf[(size_t)(t_sp - p.stack_lds) * p.ovf_stride + (blockIdx.x * BLOCK + tid)];
             };
@@ -839,21 +849,21 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 3 ? R
             //   * the leaf list has room for a whole block of appends (checked between blocks): no fullness test.
             // The crate's literal slab test (a +-0 direction component, or RT_FLAG_FULL_CHAIN) is chosen per BLOCK of
             // steps for the whole wave: it is the reference's own test, valid for every lane.
-            const uint32_t DONE = p.n_internal * (uint32_t)(LNODE_DW / 4);      // node references are offsets in 16-byte units
-            constexpr int STEPS = RT_STEPS_PER_CHECK;
+            const uint32_t DONE = p.n_internal * (uint32_t)LNODE_DW;            // node references are offsets in dwords
+            constexpr int STEPS = RT_STEPS_PER_CHECK_LTREE;
             static_assert(MAXL_LTREE > STEPS, "the leaf list must take a block of appends");
             auto step = [&](auto slow_tag) {
                 constexpr bool SLOW = decltype(slow_tag)::value;
                 const bool is_leaf = t_ref > 0x7fffu;
                 const uint32_t ni = is_leaf ? DONE : t_ref;
                 if (STATS) n_int += (ni != DONE) ? 1u : 0u;
-                const uint32_t top = (uint32_t)lstack16[(t_sp - 1u) * BLOCK + tid];
+                const uint32_t top = (uint32_t)lstack16[(t_sp - 1u) * BLOCK + tid16];
                 WCOUNT(5);
                 LCOUNT(5);
-                uint16_t* const dst = is_leaf ? &lc16[t_cnt * BLOCK + tid] : &lstack16[t_sp * BLOCK + tid];
+                uint16_t* const dst = is_leaf ? &lc16[t_cnt * BLOCK + tid16] : &lstack16[t_sp * BLOCK + tid16];
                 *dst = (uint16_t)t_ref;                          // (the flush masks the leaf flag off)
                 // Ray::intersects_aabb (ray.rs:174-194) on both child boxes; (near, far) planes fetched by sign
-                const float* __restrict__ nd = lnodes + (ni << 2);
+                const float* __restrict__ nd = lnodes + ni;
                 const float* __restrict__ fx = nd + sgx;
                 const float* __restrict__ fy = nd + 6 + sgy;
                 const float* __restrict__ fz = nd + 12 + sgz;
@@ -879,7 +889,7 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 3 ? R
                     hr = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(rxn, ryn), rzn), 0.0f) <= __builtin_fminf(__builtin_fminf(rxf, ryf), rzf);
                 }
                 const uint32_t cl = refs & 0xffffu, cr = refs >> 16;
-                lstack16[t_sp * BLOCK + tid] = (uint16_t)cr;     // right subtree after the whole left subtree
+                lstack16[t_sp * BLOCK + tid16] = (uint16_t)cr;     // right subtree after the whole left subtree
                 const bool any = hl || hr;
                 t_ref = any ? (hl ? cl : cr) : top;
                 t_sp = max(t_sp + ((hl && hr) ? 1u : 0u) - (any ? 0u : 1u), 1u);
@@ -927,7 +937,7 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 3 ? R
 #else
                         if (t_cnt == ML) continue;
 #endif
-                        if (LTREE) lc16[t_cnt * BLOCK + tid] = (uint16_t)(t_ref & 0x7fffu);
+                        if (LTREE) lc16[t_cnt * BLOCK + tid16] = (uint16_t)(t_ref & 0x7fffu);
                         else lc32[t_cnt * BLOCK + tid] = t_ref & ~LEAF_BIT;
                         t_cnt++;
                         n_cand++;
@@ -1193,7 +1203,7 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 3 ? R
                     if (p.path32)
                         reinterpret_cast<uint32_t*>(lpath)[k * BLOCK + tid] = (uint32_t)h.idx;
                     else
-                        reinterpret_cast<uint16_t*>(lpath)[k * BLOCK + tid] = (uint16_t)h.idx;
+                        reinterpret_cast<uint16_t*>(lpath)[k * BLOCK + tid16] = (uint16_t)h.idx;
                     k++;
                     depth_left--;
                     if (depth_left == 0) {
@@ -1236,7 +1246,7 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 3 ? R
                     WCOUNT(13);
                     LCOUNT(11);
                     uint32_t idx = p.path32 ? reinterpret_cast<uint32_t*>(lpath)[i * BLOCK + tid]
-                                            : (uint32_t) reinterpret_cast<uint16_t*>(lpath)[i * BLOCK + tid];
+                                            : (uint32_t) reinterpret_cast<uint16_t*>(lpath)[i * BLOCK + tid16];
                     float4 m = mat_at((uint32_t)idx);
                     term_r = m.x * term_r;
                     term_g = m.y * term_g;

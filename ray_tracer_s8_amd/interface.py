@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import ctypes as C
 import hashlib
+import threading
 import uuid
 from dataclasses import dataclass, field
 from typing import Optional, Sequence
@@ -157,16 +158,11 @@ class Scene:
                             stream: int = 0):
         """Batched, asynchronous, device-resident output (rt_scene_render_tiles_device)."""
         n = len(reqs)
-        caches = self.__dict__.setdefault("_batch_cache", {})
-        key = (id(reqs), tuple(d_out_ptrs))
-        cache = caches.get(key)
-        if cache is None:
-            if len(caches) >= 4:
-                caches.clear()
-            arr = (TileRequest * n)(*reqs)
-            po = (C.c_void_p * n)(*d_out_ptrs)
-            caches[key] = cache = (key, arr, po)
-        _abi.check(self._lib.rt_scene_render_tiles_device(self._h, cache[1], n, cache[2], out_len_each, None,
+        # marshalled afresh on every call (a few dozen structs): a cache keyed on id(reqs) served stale requests to a
+        # caller that changed seed or division_no in place
+        arr = (TileRequest * n)(*reqs)
+        po = (C.c_void_p * n)(*d_out_ptrs)
+        _abi.check(self._lib.rt_scene_render_tiles_device(self._h, arr, n, po, out_len_each, None,
                                                           C.c_void_p(stream) if stream else None),
                    "rt_scene_render_tiles_device")
 
@@ -183,8 +179,17 @@ class Slave:
         self.device = device
         self._scene: Optional[Scene] = None
         self._scene_key = None
+        # The reference slave drains its requests through ONE worker thread (slave main.rs:32-36, 159-160), so two
+        # jobs never overlap on a slave.  Callers here may be threads of different jobs (controller_shim starts a set
+        # per upload): the whole of render() — key check, scene swap, render — runs under this lock, or one job would
+        # destroy the scene the other is rendering from.
+        self._lock = threading.Lock()
 
     def render(self, info: RenderInfo) -> ImageSlice:
+        with self._lock:
+            return self._render_locked(info)
+
+    def _render_locked(self, info: RenderInfo) -> ImageSlice:
         # the reference rebuilds the BVH per strip; the scene stays resident while the world's CONTENT is the same
         # (a slave behind HTTP gets a freshly decoded world object with every strip of a job)
         w = info.world
@@ -199,9 +204,10 @@ class Slave:
         return ImageSlice(division_no=info.division_no, image=img, id=info.render_meta.id, stats=st)
 
     def close(self):
-        if self._scene:
-            self._scene.close()
-            self._scene = None
+        with self._lock:
+            if self._scene:
+                self._scene.close()
+                self._scene = None
 
 
 class Controller:
@@ -213,11 +219,27 @@ class Controller:
         self.slaves = [Slave(d) for d in self.devices]
 
     def render_frame(self, world: World, meta: RenderMeta, settings: RenderSettings) -> np.ndarray:
+        """Strip k goes to slave k mod n; the slaves work concurrently, one dispatcher thread each (the controller fires
+        its requests with join_all, controller main.rs:47-75; ctypes releases the GIL inside the render call)."""
+        results: list = [None] * len(self.slaves)
+
+        def run(w: int, slave: Slave):
+            try:
+                results[w] = [slave.render(RenderInfo(world, meta, k, settings))
+                              for k in strips_for_worker(meta.divisions, w, len(self.slaves))]
+            except BaseException as e:          # handed to the caller below
+                results[w] = e
+
+        threads = [threading.Thread(target=run, args=(w, s)) for w, s in enumerate(self.slaves)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
         slices = []
-        for w, slave in enumerate(self.slaves):
-            for k in strips_for_worker(meta.divisions, w, len(self.slaves)):
-                s = slave.render(RenderInfo(world, meta, k, settings))
-                slices.append((s.division_no, s.image))
+        for r in results:
+            if isinstance(r, BaseException):
+                raise r
+            slices += [(s.division_no, s.image) for s in r]
         return assemble(slices, meta.width, meta.height, meta.divisions)
 
     def close(self):

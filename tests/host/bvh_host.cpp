@@ -158,4 +158,53 @@ int host_bvh_check(const float* boxes, uint32_t n, uint32_t* out) {
     return 0;
 }
 
+// The product's AABB helpers (rt_bvh.h) on raw boxes, for the reference's own doc-test vectors (aabb.rs:453,474,520,565;
+// axis.rs:20,33).  out[0..2] size (as the builder forms it: hi - lo), [3..5] center, [6] surface_area, [7] largest_axis,
+// [8] is_empty(a), [9..14] join(a, b), [15..20] join(a, point box) = grow
+void host_aabb_kat(const float* a6, const float* b6, const float* pt3, float* out) {
+    rtbvh::Box a, b, pt;
+    for (int i = 0; i < 3; i++) {
+        a.lo[i] = a6[i]; a.hi[i] = a6[3 + i];
+        b.lo[i] = b6[i]; b.hi[i] = b6[3 + i];
+        pt.lo[i] = pt.hi[i] = pt3[i];
+    }
+    float c[3];
+    rtbvh::center(a, c);
+    for (int i = 0; i < 3; i++) {
+        out[i] = a.hi[i] - a.lo[i];
+        out[3 + i] = c[i];
+    }
+    out[6] = rtbvh::surface_area(a);
+    out[7] = (float)rtbvh::largest_axis(a);
+    out[8] = (a.lo[0] > a.hi[0] || a.lo[1] > a.hi[1] || a.lo[2] > a.hi[2]) ? 1.0f : 0.0f;     // aabb.rs:501-503
+    const rtbvh::Box j = rtbvh::join(a, b), g = rtbvh::join(a, pt);
+    for (int i = 0; i < 3; i++) {
+        out[9 + i] = j.lo[i]; out[12 + i] = j.hi[i];
+        out[15 + i] = g.lo[i]; out[18 + i] = g.hi[i];
+    }
+}
+void host_empty_box(float* out6) {
+    const rtbvh::Box e = rtbvh::empty_box();
+    for (int i = 0; i < 3; i++) { out6[i] = e.lo[i]; out6[3 + i] = e.hi[i]; }
+}
+// growing the empty box by one point, as the builder's centroid bounds start (aabb.rs:340-350)
+void host_empty_grow(const float* pt3, float* out6) {
+    rtbvh::Box pt;
+    for (int i = 0; i < 3; i++) pt.lo[i] = pt.hi[i] = pt3[i];
+    const rtbvh::Box g = rtbvh::join(rtbvh::empty_box(), pt);
+    for (int i = 0; i < 3; i++) { out6[i] = g.lo[i]; out6[3 + i] = g.hi[i]; }
+}
+// the walk's slab test (the restatement above of ray.rs:174-194, as the kernels evaluate it) on one box
+int host_ray_hits_box(const float* origin, const float* dir, const float* box6) {
+    const float len = sqrtf((dir[0] * dir[0] + dir[1] * dir[1]) + dir[2] * dir[2]);
+    HRay r;
+    for (int a = 0; a < 3; a++) {
+        const float d = dir[a] / len;
+        r.o[a] = origin[a];
+        r.inv[a] = 1.0f / d;
+        r.s[a] = d < 0.0f;
+    }
+    return hits(r, box6, box6 + 3) ? 1 : 0;
+}
+
 }  // extern "C"

@@ -141,3 +141,35 @@ def test_header_is_valid_c99_and_c_client_links(tmp_path):
         assert "no HIP device" in run.stderr
     else:
         assert run.returncode == 0 and "C_CLIENT_OK" in run.stdout, run.stdout + run.stderr
+
+
+def test_nothing_unwinds_across_the_boundary():
+    """rt_tile.h: "never throws or aborts across the boundary".  Every exported entry point runs its body through one
+    guard (rt_api.hip: guarded()); rt_debug_throw raises inside such a body — the status comes back, with a message."""
+    lib = _abi.load()
+    lib.rt_debug_throw.restype = C.c_int
+    lib.rt_debug_throw.argtypes = [C.c_int]
+    lib.rt_last_error.restype = C.c_char_p
+    assert lib.rt_debug_throw(0) == -9                       # std::bad_alloc -> RT_ERR_OOM
+    assert b"allocation" in lib.rt_last_error()
+    assert lib.rt_debug_throw(1) == -7                       # std::exception -> RT_ERR_HIP, what() kept
+    assert b"rt_debug_throw" in lib.rt_last_error()
+    assert lib.rt_debug_throw(2) == -7                       # anything else
+    assert lib.rt_debug_throw(3) in (-9, -7)                 # a real allocation failure (bad_alloc or length_error)
+    assert lib.rt_debug_throw(4) == 0
+
+
+def test_scene_size_limit_is_checked_before_anything_is_allocated():
+    """More primitives than the kernels' 32-bit byte offsets can address: RT_ERR_LIMIT from rt_scene_create and
+    rt_render_frame, on a box without a GPU too (argument checks come first)."""
+    lib = _abi.load()
+    sph = np.zeros(1, _abi.SPHERE_DTYPE)
+    out = C.c_void_p()
+    too_many = 0x3ffffff + 1
+    rc = lib.rt_scene_create(0, sph.ctypes.data_as(C.c_void_p), C.c_uint32(too_many), None, C.c_uint32(0), C.byref(out))
+    assert rc == -8 and not out.value
+    rq = _abi.default_request(width=8, height=8, divisions=1, spp=1)
+    buf = np.zeros(8 * 8 * 3, np.uint8)
+    rc = lib.rt_render_frame(None, 0, C.byref(rq), sph.ctypes.data_as(C.c_void_p), C.c_uint32(too_many), None, C.c_uint32(0),
+                             buf.ctypes.data_as(C.c_void_p), C.c_size_t(buf.size), None)
+    assert rc == -8

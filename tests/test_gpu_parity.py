@@ -421,6 +421,71 @@ def test_two_host_threads_on_one_device(ndev):
     assert st_a.n_launches == 2 and st_b.n_launches == 2     # [0]: six strips = five + the last under their D2H
 
 
+def test_frame_dispatcher_strip_queue_and_pinning(ndev, oracle, monkeypatch):
+    """rt_render_frame's assignments give the same frame: static strip k -> device k mod n in one batch (default),
+    and RT_FRAME_QUEUE=1 — strips pulled bottom-up from a host-atomic queue, two launches in flight per device —
+    with one and with three dispatcher threads on GPU 0, with and without the page-locked frame buffer."""
+    sph, rq = _small("c3", 256, 144, spp=3, div=12)
+    ref, st_ref = rt.render_frame_native(rt.World(sph), rq, devices=[0])
+    one = rq.copy()
+    one.divisions = 1
+    want, _, info = oracle.render(one, sph, backend=1)
+    assert np.array_equal(ref.reshape(-1), want)
+    for env in ({"RT_FRAME_QUEUE": "1"}, {"RT_FRAME_QUEUE": "1", "RT_PIN_FRAME": "0"}, {"RT_PIN_FRAME": "0"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        for devs in ([0], [0, 0, 0]):
+            img, st = rt.render_frame_native(rt.World(sph), rq, devices=devs)
+            assert np.array_equal(img, ref), (env, devs)
+            assert st.ray_segments == st_ref.ray_segments == info["ray_segments"]
+            if "RT_FRAME_QUEUE" in env:
+                assert st.n_launches == 12                   # one launch per strip
+        for k in env:
+            monkeypatch.delenv(k)
+
+
+def test_capped_stack_launches_on_two_streams(ndev, oracle, monkeypatch):
+    """The capped-stack walk (stack entries beyond a few LDS slots live in one per-scene HBM area) enqueued on two
+    streams at once: the library chains such launches, so frames rendered 'concurrently' are still exact."""
+    import torch
+    monkeypatch.setenv("RT_FORCE_CAPPED", "1")
+    monkeypatch.setenv("RT_STACK_LDS", "3")
+    sph = scenes.rand65536(n=9000)
+    rq = _abi.default_request(width=128, height=80, divisions=1, spp=2, max_bounces=5, seed=99,
+                              flags=_abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_QUANT_NODES)
+    nb = 128 * 80 * 3
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [torch.zeros(nb, dtype=torch.uint8, device="cuda") for _ in range(6)]
+    with rt.Scene(0, rt.World(sph)) as sc:
+        reqs = []
+        for i, o in enumerate(outs):
+            r = rq.copy()
+            r.seed = 99 + (i % 3)
+            reqs.append(r)
+            sc.render_tiles_device([r], [o.data_ptr()], nb, streams[i % 2].cuda_stream)
+        torch.cuda.synchronize()
+        st = sc.collect()
+    assert st.engine == 3 and st.n_launches == 6
+    for r, o in zip(reqs, outs):
+        want, _, _ = oracle.render(r, sph, backend=1)
+        assert np.array_equal(o.cpu().numpy(), want)
+
+
+def test_shutdown_is_refused_while_a_scene_is_alive(ndev):
+    """rt_shutdown used to delete the device contexts under live scenes; now it is a no-op with a message until the last
+    scene is destroyed."""
+    lib = _abi.load()
+    lib.rt_last_error.restype = C.c_char_p
+    sph, rq = _small("c2", 64, 36, spp=1, div=1)
+    with rt.Scene(0, rt.World(sph)) as sc:
+        lib.rt_shutdown()
+        assert b"refused" in lib.rt_last_error()
+        a, _, _ = sc.render_tiles([rq])                      # the scene and its context still work
+    with rt.Scene(0, rt.World(sph)) as sc2:
+        b, _, _ = sc2.render_tile(rq)
+    assert np.array_equal(a[0], b)
+
+
 def test_python_controller_and_slave_mirror(ndev, oracle):
     from ray_tracer_s8_amd.interface import Controller, RenderMeta, RenderSettings, World
     sph = scenes.cornell16()
@@ -459,6 +524,55 @@ def test_controller_shim_with_gpu_slaves(ndev, oracle):
         rq = _abi.default_request(width=96, height=64, divisions=1, spp=8, max_bounces=4, seed=5)
         ref, _, _ = oracle.render(rq, None, obj.build_world(OBJ + MTL, len(OBJ)), backend=1)
         assert np.abs(img - ref.reshape(64, 96, 3)).mean() < 6.0
+    finally:
+        ctl.stop()
+
+
+OBJ2 = b"""v -2 -1 -4
+v 2 -1 -4
+v 0 2 -4
+v -2 -1 -2
+v 2 -1 -2
+usemtl a
+f 1 2 3
+f 4 5 1
+f 5 2 1
+"""
+MTL2 = b"""newmtl a
+Kd 0.2 0.7 0.9
+Ns 100
+"""
+
+
+def test_controller_shim_two_overlapping_jobs(ndev, oracle):
+    """Two uploads with DIFFERENT worlds before the first poll (the reference controller keeps a list of concurrent
+    jobs): both jobs' dispatcher threads go through the same in-process GPU slaves.  Without the per-slave lock one
+    job destroyed the scene the other was rendering from."""
+    import io, time, urllib.request
+    PIL = pytest.importorskip("PIL.Image")
+    from ray_tracer_s8_amd import obj
+    from ray_tracer_s8_amd.controller_shim import ControllerService
+    from ray_tracer_s8_amd.interface import RenderSettings
+    from test_obj import MTL, OBJ
+    ctl = ControllerService(devices=[0, 0], host="127.0.0.1", port=0, width=96, height=64, divisions=8,
+                            settings=RenderSettings(spp=8, max_bounces=4, seed=5)).start()
+    post = lambda path, data: urllib.request.urlopen(
+        urllib.request.Request(f"http://127.0.0.1:{ctl.port}{path}", data=data, method="POST"), timeout=60).read()
+    try:
+        bodies = [(OBJ, MTL), (OBJ2, MTL2), (OBJ, MTL), (OBJ2, MTL2)]
+        jobs = [post(f"/upload/{len(o)}/", o + m).decode() for o, m in bodies]        # all four before any poll
+        for job, (o, m) in zip(jobs, bodies):
+            out = b""
+            for _ in range(600):
+                out = post("/poll", job.encode())
+                if out[:2] == b"\xff\xd8":
+                    break
+                time.sleep(0.02)
+            assert out[:2] == b"\xff\xd8", out[:60]
+            img = np.asarray(PIL.open(io.BytesIO(out)).convert("RGB")).astype(np.float64)
+            rq = _abi.default_request(width=96, height=64, divisions=1, spp=8, max_bounces=4, seed=5)
+            ref, _, _ = oracle.render(rq, None, obj.build_world(o + m, len(o)), backend=1)
+            assert np.abs(img - ref.reshape(64, 96, 3)).mean() < 6.0
     finally:
         ctl.stop()
 
