@@ -259,14 +259,19 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     // does not fit takes the capped-stack kernel.
     // stack slots per lane: up to bvh_depth pending right children (+ 1 spare); the LDS-tree kernel's branch-free step
     // adds the DONE sentinel in slot 0 and needs the free slot its unconditional stores land in
+    // output staging (rtk::STAGE_SLOTS tiles per wave): wherever the LDS plan has room for it
+    const bool want_stage = [] { const char* e = getenv("RT_NO_STAGE"); return !(e && atoi(e) != 0); }() &&
+                            ((traverse && !ltree) || streamed);     // the kernels it is compiled into (see there)
+    const bool list16 = traverse && !ltree && n_prims <= 65536u;          // 16-bit leaf-list entries: half the LDS
+    const size_t stage_bytes_wg = (size_t)rtk::STAGE_BYTES * ((ltree ? rtk::LTREE_BLOCK : rtk::BLOCK) / 64);
     const uint32_t stack_capped = sc->bvh_depth + 1;
     const uint32_t stack_need = sc->bvh_depth + (ltree ? 2u : 1u);
     uint32_t maxl = qnodes ? (uint32_t)rtk::MAXL : (uint32_t)rtk::MAXL_EXACT, stack_lds = stack_need;
     bool capped = false;
     if (traverse && qnodes) {
         const size_t per_wg = (160u * 1024u - 4096u) / 5u - 256u;     // 4 KiB of slack, 256 B static LDS
-        const size_t fixed = path_bytes + (size_t)stack_need * rtk::BLOCK * sizeof(uint32_t);
-        const size_t slot = (size_t)rtk::BLOCK * sizeof(uint32_t);
+        const size_t fixed = path_bytes + (size_t)stack_need * rtk::BLOCK * sizeof(uint32_t) + (want_stage ? stage_bytes_wg : 0);
+        const size_t slot = (size_t)rtk::BLOCK * (list16 ? sizeof(uint16_t) : sizeof(uint32_t));
         // (RT_FORCE_CAPPED / RT_STACK_LDS, read per launch: tests drive the capped-stack kernel with small trees)
         const bool force_capped = [] { const char* e = getenv("RT_FORCE_CAPPED"); return e && atoi(e) != 0; }();
         if (!force_capped && fixed + (size_t)rtk::MINL * slot <= per_wg) {
@@ -279,7 +284,8 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     }
     p.maxl = maxl;
     p.stack_lds = stack_lds;
-    size_t cand_bytes = traverse ? (size_t)maxl * rtk::BLOCK * sizeof(uint32_t)
+    p.list16 = list16 ? 1u : 0u;
+    size_t cand_bytes = traverse ? (size_t)maxl * rtk::BLOCK * (list16 ? sizeof(uint16_t) : sizeof(uint32_t))
                                  : (size_t)rtk::MAXC * rtk::BLOCK * sizeof(uint16_t);
     p.lds_path_off = (uint32_t)(geom_bytes + cand_bytes);
     const bool expanded = !traverse && sc->expanded && !(rq->flags & RT_FLAG_OC_BROAD_PHASE);
@@ -305,6 +311,12 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
         p.lds_stack_off = (uint32_t)off;
         off += (size_t)stack_need * bs * sizeof(uint16_t);
         lds = off;
+    }
+    p.lds_stage_off = 0xffffffffu;
+    if (want_stage && lds + stage_bytes_wg <= LDS_LIMIT) {
+        lds = (lds + 15) & ~(size_t)15;
+        p.lds_stage_off = (uint32_t)lds;
+        lds += stage_bytes_wg;
     }
     if (lds > LDS_LIMIT) return fail(RT_ERR_LIMIT, "LDS budget exceeded (scene chunk + path stack)");
     fill_camera(rq, p);

@@ -45,8 +45,8 @@ constexpr int BLOCK = 256;       // 4 waves
 #ifndef RT_MINWAVES_LTREE       // LDS-resident tree: one workgroup of 16 waves per CU = 4 per SIMD, 128 VGPRs
 #define RT_MINWAVES_LTREE 4
 #endif
-#ifndef RT_MINWAVES_QTRAV       // quantised-node kernels: the bound is 4, the 90-92 VGPRs they take allow 5 waves/SIMD
-#define RT_MINWAVES_QTRAV 4
+#ifndef RT_MINWAVES_QTRAV       // quantised-node kernels: 96 VGPRs, no spill slots (unbounded they take 97-99 = 4 waves/SIMD)
+#define RT_MINWAVES_QTRAV 5
 #endif
 constexpr int MAXC = RT_MAXC;    // candidate list slots per lane (per chunk)
 constexpr int CHUNK = 2048;      // max spheres per LDS chunk (32 KiB): list entries carry an 8-bit group index
@@ -71,10 +71,20 @@ constexpr int TRAV_STACK = 64;   // traversal stack entries per lane (host falls
 constexpr int MAXL = RT_MAXL;    // leaf-candidate slots per lane in traversal mode (flushed when full)
 constexpr int MINL = RT_MINL;
 constexpr int MAXL_EXACT = 7;     // exact-node kernel: fixed (see the kernel)
-constexpr int LNODE_DW = 21;      // LDS-tree kernel: dwords per staged node (see the staging code); odd, so that the
+constexpr int LNODE_DW = 19;      // LDS-tree kernel: dwords per staged node (see the staging code); odd, so that the
                                   // nodes start on all 32 banks
-constexpr int MAXL_LTREE = 12;    // LDS-tree kernel (16-bit entries): a block of RT_STEPS_PER_CHECK appends always fits
+#ifndef RT_MAXL_LTREE
+#define RT_MAXL_LTREE 12
+#endif
+constexpr int MAXL_LTREE = RT_MAXL_LTREE;     // LDS-tree kernel (16-bit entries): a block of RT_STEPS_PER_CHECK_LTREE appends always fits
 constexpr uint32_t LEAF_BIT = 0x80000000u;
+// Output staging (north_star: "coalesced HBM stores of the tile"): a wave collects the RGB8 bytes of up to STAGE_SLOTS of
+// its 64x1 tiles in LDS and writes a finished tile as 48 whole dwords = three whole 64-byte lines.  Byte stores of
+// single pixels reached HBM as partial lines: 1.3x (c3) to 13x (c5) write amplification (profiles/r01_*, r02_*).
+constexpr uint32_t STAGE_SLOTS = 3, STAGE_TILE_BYTES = 192, STAGE_BYTES = STAGE_SLOTS * STAGE_TILE_BYTES;
+constexpr uint32_t STAGE_DIRECT = 7;      // slot number of a pixel that is stored directly (no free slot, ragged tile)
+// (three slots spelt out below: as arrays the slot state left the scalar registers — 9 more VGPRs, one wave per SIMD
+// less for the quantised-node kernel)
 
 struct StripDesc {
     uint64_t seed;
@@ -97,6 +107,7 @@ struct KParams {
     uint32_t lds_path_off;
     uint32_t lds_rr_off;
     uint32_t lds_stack_off;      // traversal engine: per-lane stack, (bvh depth + 1) x 256 x u32
+    uint32_t lds_stage_off;      // output staging (STAGE_BYTES per wave); 0xffffffff: every pixel is stored directly
     uint32_t n_strips;           // strips in this launch
     uint32_t tiles_x, tiles_per_strip, n_tiles;   // tiles of 64 pixels: (1 << tile_wlog2) wide
     uint32_t tile_wlog2;         // 3: 8x8 tiles, 6: 64x1 tiles (three whole 64-B lines of RGB8 per tile row)
@@ -119,6 +130,7 @@ struct KParams {
     float q_base[3], q_step[3], q_rstep[3];   // grid: coordinate = q_base + q * q_step; q_rstep = 1 / q_step
     uint32_t root_ref;           // root reference (LEAF_BIT | prim when the tree is a single leaf)
     uint32_t maxl;               // traversal: leaf-list slots per lane (MINL..MAXL)
+    uint32_t list16;             // L2-gather traversal kernels: leaf-list entries are 16-bit (scenes of <= 65536 primitives)
     uint32_t stack_lds;          // capped quantised-node kernel: stack entries per lane kept in LDS, deeper ones go to stack_ovf
     uint32_t ovf_stride;         //   threads in the grid (stride of the overflow area)
     uint32_t* stack_ovf;         //   [entries beyond stack_lds][ovf_stride]
@@ -489,6 +501,15 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 3 ? R
     // c3-class trees; a run-time count cost it 1 %), the quantised kernels' are chosen by the host's LDS plan
     const uint32_t ML = QNODES ? p.maxl : (uint32_t)MAXL_EXACT;   // (LTREE: MAXL_LTREE, see its step)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    // the workgroup's share of the tile queue: [next | end << 32], a refill lock, and "the launch's queue is empty"
+    __shared__ unsigned long long wg_tiles;
+    __shared__ unsigned int wg_lock, wg_drained;
+    if (threadIdx.x == 0) {
+        wg_tiles = 0ull;
+        wg_lock = 0u;
+        wg_drained = 0u;
+    }
+    __syncthreads();
     float4* lgeom = reinterpret_cast<float4*>(lds_raw);          // pair layout, see KParams::geom_pk / geom_px
     const float* lgeomf = reinterpret_cast<const float*>(lds_raw);
     float* lrr = reinterpret_cast<float*>(lds_raw + p.lds_rr_off);   // EXPANDED: exact r^2 per sphere of the chunk
@@ -513,7 +534,7 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 3 ? R
     }
 
     if (LTREE) {
-        // Stage the whole tree once per workgroup, 84 bytes per node, laid out for SIGN-SELECTED plane fetches: for
+        // Stage the whole tree once per workgroup, 76 bytes per node, laid out for SIGN-SELECTED plane fetches: for
         // each axis and child the three dwords (lo, hi, lo), so that a two-dword read at dword offset s = (d.axis < 0)
         // returns (near, far) = (aabb[sign], aabb[1 - sign]) — literally ray.rs:175-176 — with no min / max / select in
         // the step.  Dwords: l.x 0-2, r.x 3-5, l.y 6-8, r.y 9-11, l.z 12-14, r.z 15-17, 18 = left | right << 16 (16-bit
@@ -534,8 +555,6 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 3 ? R
                 for (int i = 0; i < 18; i++) q[i] = qn;
                 q[18] = __uint_as_float((p.n_internal * (uint32_t)LNODE_DW) * 0x10001u);
             }
-            q[19] = 0.f;
-            q[20] = 0.f;
         }
         const uint32_t np = p.n_sph + p.n_tri;
         if (p.lds_mat_off != 0xffffffffu) {
@@ -628,10 +647,46 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 3 ? R
         n_seg = n_cand = n_fall = 0;
         n_int = 0;
     };
+    // ---- output staging (see STAGE_SLOTS).  Slot bookkeeping is wave-uniform (scalar registers): pixels still to
+    // come per slot (< 0: free) and the tile's address in the strip; only the 192 data bytes per slot live in LDS.
+    // Compiled into the kernels whose gathers churn L2 (the L2-gather walks, the streamed scan): there a pixel's line
+    // is evicted half written.  The LDS-tree and resident-scan kernels leave L2 to the frame: their byte stores merge
+    // there into whole lines (c3: WRITE_SIZE 1.03 x the frame either way, profiles/r02_*), staging only cost registers.
+    constexpr bool CAN_STAGE = (ISECT >= 1 && ISECT <= 4);
+    const bool staging = CAN_STAGE && p.lds_stage_off != 0xffffffffu;
+    unsigned char* const stage_base = lds_raw + (staging ? p.lds_stage_off + (uint32_t)(tid >> 6) * STAGE_BYTES : 0u);
+    int s_left0 = -1, s_left1 = -1, s_left2 = -1;
+    uint8_t *s_dst0 = nullptr, *s_dst1 = nullptr, *s_dst2 = nullptr;
+    uint32_t tile_slot = STAGE_DIRECT;        // slot of the wave's current tile
+    uint32_t fin_slot = STAGE_DIRECT;         // per lane: slot of the pixel it finished in the last pass
+
     TDECL;
     for (;;) {
         WCOUNT(0);
         TSTAMP(5);
+        if (staging && __ballot(fin_slot != STAGE_DIRECT)) {
+            // ================= finished tiles: LDS -> three whole lines of the strip, by whatever lanes are left
+            const unsigned long long m0 = __ballot(fin_slot == 0), m1 = __ballot(fin_slot == 1), m2 = __ballot(fin_slot == 2);
+            fin_slot = STAGE_DIRECT;
+            s_left0 -= (int)__builtin_popcountll(m0);
+            s_left1 -= (int)__builtin_popcountll(m1);
+            s_left2 -= (int)__builtin_popcountll(m2);
+            if (s_left0 == 0 || s_left1 == 0 || s_left2 == 0) {
+                const unsigned long long act = __ballot(true);
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
+                const uint32_t nact = (uint32_t)__builtin_popcountll(act);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // the byte stores of this wave's other lanes
+                auto put = [&](uint32_t sl, uint8_t* dst) {
+                    const uint32_t* src = reinterpret_cast<const uint32_t*>(stage_base + sl * STAGE_TILE_BYTES);
+                    uint32_t* d32 = reinterpret_cast<uint32_t*>(dst);
+                    for (uint32_t i = rank; i < STAGE_TILE_BYTES / 4; i += nact) d32[i] = src[i];
+                };
+                if (s_left0 == 0) { put(0, s_dst0); s_left0 = -1; }
+                if (s_left1 == 0) { put(1, s_dst1); s_left1 = -1; }
+                if (s_left2 == 0) { put(2, s_dst2); s_left2 = -1; }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // reads done before the slot is written again
+            }
+        }
         if (TRAVERSE && __ballot(((n_seg | n_cand | n_fall | n_int) & 0x80000000u) != 0)) drain_counters();
         // ================= pixel acquisition: lanes pull pixels of the wave's current tile
         {
@@ -640,11 +695,48 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 3 ? R
                 unsigned long long mask = __ballot(need);
                 if (mask == 0) break;
                 if (tile_pos >= 64) {                         // wave-uniform: fetch the next tile
+                    // Two-level tile queue.  The launch's queue head is shared by all eight XCDs, so every atomic on it
+                    // is a memory-side operation (one per tile: 6 MB of "write" traffic per 4K frame on top of 25 MB of
+                    // pixels, profiles/).  A workgroup therefore takes WGC = one tile per wave at a time from it and hands
+                    // them to its waves through an LDS counter pair: tile-granular balance inside the workgroup, and the
+                    // launch tail still one tile per wave long (waves taking private runs of tiles left 10-25 % between
+                    // the average and the last wave, tools/ab.sh).
                     unsigned long long live = __ballot(true);
-                    uint32_t t = 0;
-                    if (lane == (int)__builtin_ctzll(live)) t = (uint32_t)atomicAdd(p.queue, 1ull);
+                    uint32_t t = 0xffffffffu;
+                    if (lane == (int)__builtin_ctzll(live)) {
+                        constexpr uint32_t WGC = (uint32_t)(BLOCK / 64);
+                        for (;;) {
+                            const unsigned long long old = __hip_atomic_fetch_add(&wg_tiles, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if ((uint32_t)old < (uint32_t)(old >> 32)) {
+                                t = (uint32_t)old;
+                                break;
+                            }
+                            if (__hip_atomic_load(&wg_drained, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+                            if (__hip_atomic_exchange(&wg_lock, 1u, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) {
+                                // this wave refills (unless another one just did)
+                                const unsigned long long cur = __hip_atomic_load(&wg_tiles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                bool done = false;
+                                if ((uint32_t)cur >= (uint32_t)(cur >> 32)) {
+                                    const uint32_t g = (uint32_t)atomicAdd(p.queue, (unsigned long long)WGC);
+                                    if (g >= p.n_tiles) {
+                                        __hip_atomic_store(&wg_drained, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    } else {
+                                        t = g;                                    // the first one is this wave's
+                                        const uint32_t ge = min(g + WGC, p.n_tiles);
+                                        __hip_atomic_store(&wg_tiles, (unsigned long long)(g + 1u) | ((unsigned long long)ge << 32),
+                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    }
+                                    done = true;
+                                }
+                                __hip_atomic_store(&wg_lock, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                if (done) break;
+                            } else {
+                                __builtin_amdgcn_s_sleep(2);                      // another wave is refilling
+                            }
+                        }
+                    }
                     t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-                    if (t >= p.n_tiles) {                     // queue drained: needy lanes retire
+                    if (t == 0xffffffffu) {                   // queue drained: needy lanes retire
                         if (need) retired = true;
                         break;
                     }
@@ -664,6 +756,16 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 3 ? R
                     tile_yg0 = p.strips[st].y0;
                     tile_seed = p.strips[st].seed;
                     tile_pos = 0;
+                    tile_slot = STAGE_DIRECT;
+                    if (staging && p.tile_wlog2 == 6 && tile_x0 + 64u <= p.W && tile_y0 < p.Hs) {
+                        // a whole 64x1 tile whose 192 bytes start dword-aligned: stage it if a slot is free
+                        uint8_t* dst = p.strips[st].rgb + ((size_t)tile_y0 * p.W + tile_x0) * 3;
+                        if ((reinterpret_cast<uintptr_t>(dst) & 3u) == 0) {
+                            if (s_left0 < 0) { tile_slot = 0; s_left0 = 64; s_dst0 = dst; }
+                            else if (s_left1 < 0) { tile_slot = 1; s_left1 = 64; s_dst1 = dst; }
+                            else if (s_left2 < 0) { tile_slot = 2; s_left2 = 64; s_dst2 = dst; }
+                        }
+                    }
                 }
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
                                                                 __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
@@ -676,7 +778,7 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 3 ? R
                     const uint32_t x = tile_x0 + (pidx & ((1u << p.tile_wlog2) - 1u)), y = tile_y0 + (pidx >> p.tile_wlog2);
                     if (x < p.W && y < p.Hs) {
                         px = x;
-                        strip = tile_strip;
+                        strip = tile_strip | (tile_slot << 8);       // strip index in the batch, staging slot of the pixel's tile
                         const uint32_t yg = tile_yg0 + y;                         // main.rs:66-68
                         pyg = yg;
                         rng = seed_pixel(tile_seed, (uint64_t)yg * p.W + x);
@@ -787,7 +889,8 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 3 ? R
 #pragma clang loop unroll(disable)
                 for (uint32_t i = 0; i < t_cnt; i++) {
                     LCOUNT(6);
-                    const uint32_t prim = LTREE ? (uint32_t)lc16[i * BLOCK + tid16] & 0x7fffu : lc32[i * BLOCK + tid];
+                    const uint32_t prim = LTREE ? (uint32_t)lc16[i * BLOCK + tid16] & 0x7fffu
+                                          : p.list16 ? (uint32_t)lc16[i * BLOCK + tid16] : lc32[i * BLOCK + tid];
                     float t;
                     // The quantised walk only over-approximates BVH::traverse, so a leaf it delivers counts iff
                     // the reference would have reached it = its own exact box passes (leaf-box lemma, bvh_reaches;
@@ -937,7 +1040,7 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 3 ? R
 #else
                         if (t_cnt == ML) continue;
 #endif
-                        if (LTREE) lc16[t_cnt * BLOCK + tid16] = (uint16_t)(t_ref & 0x7fffu);
+                        if (p.list16) lc16[t_cnt * BLOCK + tid16] = (uint16_t)t_ref;        // (prims <= 65536: the id's low 16 bits)
                         else lc32[t_cnt * BLOCK + tid] = t_ref & ~LEAF_BIT;
                         t_cnt++;
                         n_cand++;
@@ -1264,12 +1367,21 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 3 ? R
                     float r = __builtin_sqrtf(sum_r / p.spp_f);
                     float g = __builtin_sqrtf(sum_g / p.spp_f);
                     float b = __builtin_sqrtf(sum_b / p.spp_f);
-                    size_t oidx = ((size_t)(pyg - p.strips[strip].y0) * p.W + px) * 3;      // row within the strip
-                    uint8_t* orgb = p.strips[strip].rgb;
-                    orgb[oidx + 0] = f32_as_u8(r * 255.999f);
-                    orgb[oidx + 1] = f32_as_u8(g * 255.999f);
-                    orgb[oidx + 2] = f32_as_u8(b * 255.999f);
-                    float* of = p.strips[strip].f32;
+                    const uint32_t pslot = strip >> 8, sidx = strip & 0xffu;
+                    size_t oidx = ((size_t)(pyg - p.strips[sidx].y0) * p.W + px) * 3;      // row within the strip
+                    if (pslot == STAGE_DIRECT) {
+                        uint8_t* orgb = p.strips[sidx].rgb;
+                        orgb[oidx + 0] = f32_as_u8(r * 255.999f);
+                        orgb[oidx + 1] = f32_as_u8(g * 255.999f);
+                        orgb[oidx + 2] = f32_as_u8(b * 255.999f);
+                    } else {
+                        volatile uint8_t* sd = stage_base + pslot * STAGE_TILE_BYTES + (px & 63u) * 3u;
+                        sd[0] = f32_as_u8(r * 255.999f);
+                        sd[1] = f32_as_u8(g * 255.999f);
+                        sd[2] = f32_as_u8(b * 255.999f);
+                        fin_slot = pslot;
+                    }
+                    float* of = p.strips[sidx].f32;
                     if (of) {
                         of[oidx + 0] = r;
                         of[oidx + 1] = g;

@@ -447,28 +447,43 @@ def test_frame_dispatcher_strip_queue_and_pinning(ndev, oracle, monkeypatch):
 def test_capped_stack_launches_on_two_streams(ndev, oracle, monkeypatch):
     """The capped-stack walk (stack entries beyond a few LDS slots live in one per-scene HBM area) enqueued on two
     streams at once: the library chains such launches, so frames rendered 'concurrently' are still exact."""
-    import torch
+    hip = C.CDLL("libamdhip64.so")
     monkeypatch.setenv("RT_FORCE_CAPPED", "1")
     monkeypatch.setenv("RT_STACK_LDS", "3")
     sph = scenes.rand65536(n=9000)
     rq = _abi.default_request(width=128, height=80, divisions=1, spp=2, max_bounces=5, seed=99,
                               flags=_abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_QUANT_NODES)
     nb = 128 * 80 * 3
-    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
-    outs = [torch.zeros(nb, dtype=torch.uint8, device="cuda") for _ in range(6)]
-    with rt.Scene(0, rt.World(sph)) as sc:
+    with rt.Scene(0, rt.World(sph)) as sc:                   # (the scene makes device 0 current for this thread)
+        streams, outs = [], []
+        for _ in range(2):
+            st_ = C.c_void_p()
+            assert hip.hipStreamCreate(C.byref(st_)) == 0
+            streams.append(st_)
+        for _ in range(6):
+            d = C.c_void_p()
+            assert hip.hipMalloc(C.byref(d), C.c_size_t(nb)) == 0
+            outs.append(d)
         reqs = []
         for i, o in enumerate(outs):
             r = rq.copy()
             r.seed = 99 + (i % 3)
             reqs.append(r)
-            sc.render_tiles_device([r], [o.data_ptr()], nb, streams[i % 2].cuda_stream)
-        torch.cuda.synchronize()
+            sc.render_tiles_device([r], [o.value], nb, streams[i % 2].value)
+        assert hip.hipDeviceSynchronize() == 0
         st = sc.collect()
+        got = []
+        for o in outs:
+            h = np.zeros(nb, np.uint8)
+            assert hip.hipMemcpy(h.ctypes.data_as(C.c_void_p), o, C.c_size_t(nb), 2) == 0      # hipMemcpyDeviceToHost
+            got.append(h)
+            hip.hipFree(o)
+        for s_ in streams:
+            hip.hipStreamDestroy(s_)
     assert st.engine == 3 and st.n_launches == 6
-    for r, o in zip(reqs, outs):
+    for r, h in zip(reqs, got):
         want, _, _ = oracle.render(r, sph, backend=1)
-        assert np.array_equal(o.cpu().numpy(), want)
+        assert np.array_equal(h, want)
 
 
 def test_shutdown_is_refused_while_a_scene_is_alive(ndev):

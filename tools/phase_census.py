@@ -2,7 +2,7 @@
 """Phase census: build with -DRT_PROFILE_PHASES, render one c3 frame, print per-wave-iteration counts."""
 import ctypes as C, os, sys
 sys.path.insert(0, ".")
-os.environ["RT_EXTRA_HIPCC_FLAGS"] = "-DRT_PROFILE_PHASES"
+os.environ["RT_EXTRA_HIPCC_FLAGS"] = "-DRT_PROFILE_PHASES " + os.environ.get("RT_PT_FLAGS", "")
 from ray_tracer_s8_amd import build
 build.build(force=True)
 import numpy as np, torch

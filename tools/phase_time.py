@@ -3,7 +3,7 @@
 usage: tools/phase_time.py [config] [flags]"""
 import ctypes as C, os, sys
 sys.path.insert(0, ".")
-os.environ["RT_EXTRA_HIPCC_FLAGS"] = "-DRT_PROFILE_TIME"
+os.environ["RT_EXTRA_HIPCC_FLAGS"] = "-DRT_PROFILE_TIME " + os.environ.get("RT_PT_FLAGS", "")
 from ray_tracer_s8_amd import build
 build.build(force=True)
 import ray_tracer_s8_amd as rt
