@@ -2,20 +2,25 @@
 """Benchmark of the hot path: Mrays/s of the HIP tile renderer on BASELINE config c3
 (1024 random spheres, 3840x2160, 8 spp, depth 8), strips sharded over N GPUs.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload c2|c3|c4|c5|mesh] [--strong]
 
-A "step" is one pass of the hot path over one batch of synthetic input: every rank renders the
-strips it owns of the job (N frames of c3 at N GPUs — weak scaling, unit (frame f, strip d) goes
-to rank (f + d) % N, no collective on the data path).  The scene is resident in HBM before
-the timed region; output strips are written to HBM.  Timing: barrier + synchronize on both
-sides of exactly K steps, MAX over ranks.  value = ray segments of all ranks / that time.
+A "step" is one pass of the hot path over one batch of synthetic input: every rank renders the strips it owns of the
+job.  Default = weak scaling: N frames of the workload at N GPUs, unit (frame f, strip d) goes to rank (f + d) % N.
+--strong = the controller's split that BASELINE configs 4 and 5 name: ONE frame, strip d goes to rank d % N.  No
+collective on the data path either way.  The scene is resident in HBM before the timed region; output strips are written
+to HBM.  Timing: barrier + synchronize on both sides of exactly K steps, MAX over ranks.  value = ray segments of all
+ranks / that time.
 
-Also reported in the same JSON line:
-  roofline      the dominant kernel against the FP32 VALU peak with SURVEY §8(d)'s algorithmic
-                20*N flops per ray segment; avg launch duration from HIP events recorded by the
-                library on the stream the kernel runs on
-  cpu_baseline  the CPU oracle (BVH back-end = the reference's algorithm) timed on this box's
-                host cores on a bounded sample, rank 0 at N=1 only.  A baseline, not the target.
+Also reported in the same JSON line (DESIGN.md 5):
+  roofline         the timed kernel against the FP32 VALU peak, from work it EXECUTES: for the traversal engines the
+                   slab tests (48 flop per node visited) and root tests (20 flop per leaf reached), both counted by one
+                   extra launch of the same frame through the kernel's counting twin, outside the timed region; avg
+                   launch duration from HIP events recorded by the library on the stream the kernel runs on.  frac <= 1
+                   is asserted.  valu_issue / traffic come from committed PMC passes and say so ("source").
+  roofline_linear  the same frame through the north-star-shaped kernel (linear scan over the LDS-resident sphere list),
+                   own launches in this run: SURVEY 8(d)'s 20*N flop per segment / launch time
+  cpu_baseline     the CPU oracle (BVH back-end = the reference's algorithm) timed on this box's host cores on a
+                   bounded sample, rank 0 at N=1 only.  A baseline, not the target.
 """
 from __future__ import annotations
 
@@ -34,6 +39,7 @@ PEAK_FP32_VALU_TFLOPS = 157.3      # MI355X_MICROARCH.md: peak FP32 vector (FMA 
 PEAK_HBM_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FLOPS_PER_TEST = 20                # faithful ray-sphere test = 20 flop + 1 sqrt
 FLOPS_PER_NODE_STEP = 48           # two child-box slab tests: 2 x (6 sub + 6 mul + 12 min / max / compare)
+FLOPS_PER_TRI_TEST = 45            # two-sided Moller-Trumbore (mesh.rs:109-161): 2 cross (9), 4 dot (5), 2 sub (3), 1 div
 
 
 def parse_args():
@@ -41,7 +47,9 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "c5"])
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "c5", "mesh"],
+                    help="BASELINE configs c2-c5, or `mesh`: a generated 100 352-triangle OBJ through the controller's ingest "
+                         "rules at the controller's literal 1920x1080 / 20 strips (not a BASELINE config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlap", type=int, default=0, metavar="N", help="NOT the contract's measurement: consecutive steps go to N streams "
                     "with N output buffers, so that a launch starts filling the GPU while the previous one drains its "
@@ -77,13 +85,13 @@ def cpu_baseline(workload: str, scale: int):
     """Time the oracle (test infrastructure, used here only as the reported CPU baseline)."""
     from oracle import oracle as orc
     from ray_tracer_s8_amd import scenes
-    sph, rq = scenes.config(workload)
+    sph, tri, rq = scenes.config_world(workload)
     rq.width //= scale
     rq.height //= scale
     rq.divisions = 1
     rq.division_no = 0
     threads = effective_cpus()
-    _, _, info = orc.render(rq, sph, backend=1, nthreads=threads)
+    _, _, info = orc.render(rq, sph if len(sph) else None, tri if len(tri) else None, backend=1, nthreads=threads)
     secs = info["render_ms"] / 1e3
     return {
         "value": info["ray_segments"] / secs / 1e6,
@@ -133,7 +141,7 @@ def main():
 
     n_dev = rt.init()
     assert dev_index < n_dev
-    sph, rq0 = scenes.config(args.workload)
+    sph, tri, rq0 = scenes.config_world(args.workload)
     rq0.flags = args.flags
     if args.strong:
         # the controller's split of ONE frame (controller main.rs:47-75): strip d -> rank d mod N
@@ -147,7 +155,7 @@ def main():
     strip_bytes = (rq0.height // rq0.divisions) * rq0.width * 3
     out = torch.empty(len(units) * strip_bytes, dtype=torch.uint8, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream   # kernels and torch.cuda.synchronize share it
-    scene = rt.Scene(dev_index, rt.World(sph))         # world resident in HBM before timing
+    scene = rt.Scene(dev_index, rt.World(sph, tri))    # world resident in HBM before timing
 
     reqs = []
     for (f, d) in units:
@@ -218,7 +226,7 @@ def main():
         th1 = time.perf_counter()
         pcie = {"ms_per_frame_host_buffers": (th1 - th0) * 1e3, "kernel_ms": st_h.kernel_ms, "d2h_ms": st_h.d2h_ms,
                 "mrays_per_s": float(st_h.ray_segments) / (th1 - th0) / 1e6,
-                "scene_h2d_bytes": int(36 * len(sph))}
+                "scene_h2d_bytes": int(36 * len(sph) + 56 * len(tri))}
 
     # ---- work census for the roofline object (rank 0, outside the timed region): one more launch of the same
     # frame through the kernel's counting twin (RT_FLAG_COUNT_STEPS: same image, also counts the BVH nodes visited).
@@ -238,7 +246,7 @@ def main():
     # ---- the north-star-shaped kernel beside it: linear scan over the LDS-resident primitive list (flags 32), the engine
     # that performs SURVEY 8(d)'s N exact-or-conservative sphere tests per segment.  Own launches, own HIP-event timing.
     linear = None
-    if rank == 0 and world == 1 and st.engine >= 2 and len(sph) <= 2048 and not args.no_linear and not args.overlap:
+    if rank == 0 and world == 1 and st.engine >= 2 and len(sph) <= 2048 and not len(tri) and not args.no_linear and not args.overlap:
         lreqs = []
         for r in reqs:
             c = r.copy()
@@ -271,17 +279,18 @@ def main():
             # executed work of the traversal engines: per internal node visited two child-box slab tests
             # (2 x (6 sub + 6 mul + 12 min / max / compare) = 48 flop), per leaf reached one exact root test (20 flop + sqrt)
             scale = segs_per_launch / max(census["segments"], 1)          # launches of the step = census launch (1.0)
-            flops_per_launch = (census["node_steps"] * FLOPS_PER_NODE_STEP + census["root_tests"] * FLOPS_PER_TEST) * scale
+            per_root = FLOPS_PER_TRI_TEST if (len(tri) and not len(sph)) else FLOPS_PER_TEST
+            flops_per_launch = (census["node_steps"] * FLOPS_PER_NODE_STEP + census["root_tests"] * per_root) * scale
             work = {"node_steps_per_segment": census["node_steps"] / max(census["segments"], 1),
                     "root_tests_per_segment": census["root_tests"] / max(census["segments"], 1),
-                    "flops_per_node_step": FLOPS_PER_NODE_STEP, "flops_per_root_test": FLOPS_PER_TEST,
+                    "flops_per_node_step": FLOPS_PER_NODE_STEP, "flops_per_root_test": per_root,
                     "source": "counting twin of the timed kernel, one extra launch of the same frame in this run"}
         else:
             flops_per_launch = segs_per_launch * FLOPS_PER_TEST * n_sph
             work = {"tests_per_segment": n_sph, "flops_per_test": FLOPS_PER_TEST,
                     "source": "SURVEY 8(d): the linear engine tests every sphere against every segment"}
         achieved_tflops = flops_per_launch / avg_launch_s / 1e12
-        hbm_bytes_per_launch = strip_bytes * len(reqs) / max(len(batches), 1) + 36 * n_sph   # RGB8 out + scene in
+        hbm_bytes_per_launch = strip_bytes * len(reqs) / max(len(batches), 1) + 36 * n_sph + 56 * len(tri)   # RGB8 out + scene in
 
         def committed(name):
             fp = ROOT / "profiles" / name
@@ -313,7 +322,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.workload}: {n_sph} spheres, {rq0.width}x{rq0.height}, {rq0.spp} spp, "
+                "workload": f"{args.workload}: {n_sph} spheres, {len(tri)} triangles, {rq0.width}x{rq0.height}, {rq0.spp} spp, "
                             f"depth {rq0.max_bounces}, {rq0.divisions} strips/frame, "
                             + (f"ONE frame, strip d -> rank d mod {world} (controller split)" if args.strong else
                                f"{n_frames} frame(s) sharded by strip over {world} GPU(s)"),

@@ -96,8 +96,8 @@ enum {
     /* Walk the whole root-to-leaf AABB chain when validating a hit instead of using the
      * leaf-box monotonicity shortcut (A/B testing; identical images). */
     RT_FLAG_FULL_CHAIN = 1u << 3,
-    /* Closest-hit engine.  Default: linear scan over the LDS-resident / LDS-streamed primitive list for
-     * scenes up to 384 primitives, per-lane traversal of the reference BVH above that.  Both give the
+    /* Closest-hit engine.  Default: linear scan over the LDS-resident primitive list for scenes up to 48
+     * spheres (and no mesh), per-lane traversal of the reference BVH above that.  Both give the
      * reference's result bit for bit; these force one or the other (A/B runs, tests). */
     RT_FLAG_BVH_TRAVERSE = 1u << 4,
     RT_FLAG_LINEAR_SCAN = 1u << 5,

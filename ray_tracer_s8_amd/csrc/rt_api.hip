@@ -84,9 +84,9 @@ constexpr size_t LDS_LIMIT = 160 * 1024 - 1024;   // dynamic LDS budget; 1 KiB l
 constexpr uint32_t RESIDENT_MAX = rtk::CHUNK;   // spheres kept wholly in LDS
 constexpr uint32_t STREAM_CHUNK = 2048;         // chunk size when streaming through LDS
 constexpr uint32_t STACK_LDS_MAX = 12;          // quantised-node kernel: stack entries per lane in LDS, deeper ones in HBM
-constexpr uint32_t TRAVERSE_MIN_TRIS = 64;      // ... or above this many triangles
+constexpr uint32_t TRAVERSE_MIN_TRIS = 4;       // ... or above this many triangles (tools/crossover_tris.py: the LDS-tree walk wins from 8 triangles up)
 constexpr uint32_t RT_QNODES_MIN_PRIMS = 4096;   // from here up the traversal walks the 32-byte quantised nodes (tools/crossover_q.py)
-constexpr uint32_t TRAVERSE_MIN_PRIMS = 384;    // above this many primitives the BVH-traversal engine is the default (measured crossover, tools/crossover.py: 0.92 at 256, 1.11 at 512)
+constexpr uint32_t TRAVERSE_MIN_PRIMS = 48;     // above this many primitives the BVH-traversal engine is the default (measured crossover with the LDS-resident tree, tools/crossover.py: 0.91 at 16, 1.03 at 32, 1.10 at 64, 2.0 at 512)
 
 }  // namespace
 

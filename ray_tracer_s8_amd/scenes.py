@@ -145,6 +145,48 @@ def tri_terrain(nx: int = 16, nz: int = 12, seed: int = 0x7E44A1) -> tuple[np.nd
     return np.array(sph, dtype=SPHERE_DTYPE), np.array(tris, dtype=TRIANGLE_DTYPE)
 
 
+def terrain_obj(nx: int = 224, nz: int = 224, seed: int = 0x0B1E5) -> tuple[bytes, bytes]:
+    """(OBJ text, MTL text) of a rolling height field of 2*nx*nz triangles in four materials (224 x 224: 100 352
+    triangles) — the shape of input the shipped controller produces: OBJ upload -> tobj -> `Object::Triangle` list
+    (controller obj.rs:10-53).  Deterministic; vertices are written with 6 decimals, i.e. what a client would send."""
+    import math
+    g = SplitMix64(seed)
+    ph = [g.u(0.0, 6.28) for _ in range(6)]
+
+    def h(x: float, z: float) -> float:
+        return (-1.4 + 0.45 * math.sin(0.9 * x + ph[0]) * math.cos(0.7 * z + ph[1]) + 0.18 * math.sin(2.3 * x + 1.7 * z + ph[2])
+                + 0.06 * math.sin(7.1 * x + ph[3]) * math.sin(6.3 * z + ph[4]))
+
+    lines = ["# generated height field", "mtllib terrain.mtl"]
+    for k in range(nz + 1):
+        z = -1.5 - 22.0 * k / nz
+        for i in range(nx + 1):
+            x = -14.0 + 28.0 * i / nx
+            lines.append(f"v {x:.6f} {h(x, z):.6f} {z:.6f}")
+    names = ["grass", "rock", "wet", "snow"]
+    cur = None
+    for k in range(nz):
+        for i in range(nx):
+            m = names[(int(g.f() * 2.0) + (i // 28) + (k // 28)) % 4]
+            if m != cur:
+                lines.append(f"usemtl {m}")
+                cur = m
+            a = k * (nx + 1) + i + 1
+            b, c, d = a + 1, a + nx + 1, a + nx + 2
+            lines.append(f"f {a} {b} {d}")
+            lines.append(f"f {a} {d} {c}")
+    mtl = ("newmtl grass\nKd 0.25 0.55 0.2\nNs 0\nnewmtl rock\nKd 0.5 0.45 0.4\nNs 120\n"
+           "newmtl wet\nKd 0.7 0.75 0.8\nNs 900\nnewmtl snow\nKd 0.92 0.92 0.95\nNs 30\n")
+    return ("\n".join(lines) + "\n").encode(), mtl.encode()
+
+
+def mesh_world(nx: int = 224, nz: int = 224) -> np.ndarray:
+    """The triangle list the controller would build from terrain_obj() (through obj.build_world)."""
+    from . import obj
+    o, m = terrain_obj(nx, nz)
+    return obj.build_world(o + m, len(o))
+
+
 # ---- BASELINE.json configs -------------------------------------------------------------
 def config(name: str) -> tuple[np.ndarray, TileRequest]:
     """(spheres, request template) for c1..c5.  `divisions` is chosen so H % div == 0."""
@@ -162,4 +204,16 @@ def config(name: str) -> tuple[np.ndarray, TileRequest]:
     if name == "c5":
         return rand65536(), default_request(width=3840, height=2160, divisions=16, spp=8, max_bounces=8,
                                             seed=0x5EED1000)
+    if name == "mesh":
+        # not a BASELINE config: the only primitive the shipped controller emits, at the controller's literal frame
+        # (1920x1080, 20 strips); spheres = none, triangles = mesh_world()
+        return np.zeros(0, SPHERE_DTYPE), default_request(width=1920, height=1080, divisions=20, spp=4, max_bounces=4,
+                                                          seed=0x0B1E5)
     raise KeyError(name)
+
+
+def config_world(name: str):
+    """(spheres, triangles, request template): config() plus the triangle list of the mesh workload."""
+    sph, rq = config(name)
+    tri = mesh_world() if name == "mesh" else np.zeros(0, TRIANGLE_DTYPE)
+    return sph, tri, rq

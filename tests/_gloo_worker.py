@@ -21,10 +21,16 @@ from ray_tracer_s8_amd import dispatch, scenes  # noqa: E402
 def main():
     dist.init_process_group(backend="gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
+    strong = len(sys.argv) > 1 and sys.argv[1] == "strong"
     sph, rq0 = scenes.config("c2")
     rq0.width, rq0.height, rq0.divisions, rq0.spp = 64, 48, 6, 2
-    n_frames = world
-    units = dispatch.job_shards(n_frames, rq0.divisions, rank, world)
+    if strong:
+        # bench.py --strong = the controller's split of ONE frame (BASELINE c4 / c5): strip d -> rank d mod N
+        n_frames = 1
+        units = [(0, d) for d in dispatch.strips_for_worker(rq0.divisions, rank, world)]
+    else:
+        n_frames = world
+        units = dispatch.job_shards(n_frames, rq0.divisions, rank, world)
     t0 = time.perf_counter()
     mine, segs = [], 0
     for f, d in units:
@@ -55,8 +61,12 @@ def main():
             total += info["ray_segments"]
         assert int(c.item()) == total
         owners = sorted(len(p) for p in gathered)
-        assert owners == [rq0.divisions] * world              # weak scaling: equal work per rank
-        print(f"GLOO_OK world={world} frames={n_frames} segments={total}")
+        if strong:
+            assert owners == [rq0.divisions // world] * world  # strong scaling: the frame's strips split evenly
+            assert sorted(d for part in gathered for (_, d, _) in part) == list(range(rq0.divisions))
+        else:
+            assert owners == [rq0.divisions] * world          # weak scaling: equal work per rank
+        print(f"GLOO_OK world={world} frames={n_frames} segments={total} mode={'strong' if strong else 'weak'}")
     dist.destroy_process_group()
 
 

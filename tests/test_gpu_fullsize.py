@@ -13,7 +13,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 import ray_tracer_s8_amd as rt
-from ray_tracer_s8_amd import scenes
+from ray_tracer_s8_amd import _abi, scenes
 
 TOL_MEAN_ABS = 1e-5      # BASELINE.json: mean per-channel |delta| <= 1e-5 vs CPU (we get 0)
 
@@ -162,3 +162,26 @@ def test_checksum_of_strip_checksums_is_reproducible(ndev):
             h.update(hashlib.sha256(rgb[k * strip:(k + 1) * strip].tobytes()).digest())
         digests.append(h.hexdigest())
     assert digests[0] == digests[1]
+
+
+@pytest.mark.parametrize("flags", [0, 64, 64 | 256, 128])
+def test_mesh_of_100k_triangles(ndev, oracle, flags):
+    """The only primitive the shipped controller emits (controller obj.rs:27), at the scale SURVEY 8f-2 names: a generated
+    100 352-triangle OBJ through the controller's ingest rules (obj.build_world), every traversal engine against the oracle."""
+    tri = scenes.mesh_world()
+    assert len(tri) == 100352
+    rq = _abi.default_request(width=160, height=90, divisions=3, spp=3, max_bounces=4, seed=0x0B1E5, flags=flags)
+    with rt.Scene(0, rt.World(triangles=tri)) as sc:
+        reqs = []
+        for k in range(3):
+            r = rq.copy()
+            r.division_no = k
+            reqs.append(r)
+        outs, _, st = sc.render_tiles(reqs)
+    one = rq.copy()
+    one.divisions = 1
+    one.flags = 0
+    ref, _, info = oracle.render(one, None, tri, backend=1)
+    assert np.array_equal(np.concatenate(outs), ref)
+    assert st.ray_segments == info["ray_segments"]
+    assert st.engine == (2 if flags & 64 else 3)

@@ -5,6 +5,7 @@ set -e
 TAG=${1:-r02}; shift || true
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
+echo "python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pcie --no-linear $@" > $OUT/cmd.txt
 export TMPDIR=/tmp
 ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-pcie --no-linear $@"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $ARGS > $OUT/trace.log 2>&1
