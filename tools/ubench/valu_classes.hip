@@ -47,6 +47,9 @@ constexpr int ITER = 2048;
 #define I_MAXF(n) "v_max_f32 %" #n ", %" #n ", %8\n"
 #define I_FMAMIX(n) "v_fma_mix_f32 %" #n ", %" #n ", %8, %9 op_sel_hi:[1,0,0]\n"
 #define I_SDWA(n) "v_cvt_f32_u32_sdwa %" #n ", %" #n " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n"
+#define I_PAIRV(n) "v_cmp_lt_f32 vcc, %" #n ", %8\n s_nop 1\n v_cndmask_b32 %" #n ", %" #n ", %9, vcc\n"
+#define I_PAIRS(n) "v_cmp_lt_f32 s[20:21], %" #n ", %8\n s_nop 1\n v_cndmask_b32 %" #n ", %" #n ", %9, s[20:21]\n"
+#define I_CNDV64(n) "v_cndmask_b32_e64 %" #n ", %" #n ", %8, vcc\n"
 #define I_MAD64(n) "v_mad_u64_u32 v[40:41], s[20:21], %" #n ", %8, v[40:41]\n"
 
 template <int MODE>
@@ -89,6 +92,9 @@ __global__ __launch_bounds__(256) void k(float* out, float a, float b) {
         if (MODE == 32) R8(I_MAXF);
         if (MODE == 33) R8(I_FMAMIX);
         if (MODE == 34) R8(I_SDWA);
+        if (MODE == 35) R8(I_PAIRV);
+        if (MODE == 36) R8(I_PAIRS);
+        if (MODE == 37) R8(I_CNDV64);
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7;
 }
@@ -135,6 +141,9 @@ int main() {
     run<27>("v_mad_u64_u32", d_out);
     run<9>("v_cndmask_b32", d_out);
     run<28>("v_cndmask sgpr mask", d_out);
+    run<37>("v_cndmask_e64 vcc", d_out);
+    run<35>("cmp+nop+cndmask vcc (x3 instr)", d_out);
+    run<36>("cmp+nop+cndmask sgpr", d_out);
     run<29>("v_cndmask e64 2src", d_out);
     run<30>("v_med3_f32", d_out);
     run<31>("v_min3_f32", d_out);
