@@ -486,6 +486,20 @@ def test_capped_stack_launches_on_two_streams(ndev, oracle, monkeypatch):
         assert np.array_equal(h, want)
 
 
+def test_frame_over_two_devices(ndev, oracle, monkeypatch):
+    """rt_render_frame over devices [0, 1] (and the strip queue over them): the same frame as one device.  Needs a box with
+    two GPUs; the one-GPU boxes of rounds 1-2 skip it."""
+    if ndev < 2:
+        pytest.skip("needs two GPUs")
+    sph, rq = _small("c3", 256, 144, spp=3, div=12)
+    ref, st_ref = rt.render_frame_native(rt.World(sph), rq, devices=[0])
+    img, st = rt.render_frame_native(rt.World(sph), rq, devices=[0, 1])
+    assert np.array_equal(img, ref) and st.ray_segments == st_ref.ray_segments
+    monkeypatch.setenv("RT_FRAME_QUEUE", "1")
+    img, st = rt.render_frame_native(rt.World(sph), rq, devices=[1, 0])
+    assert np.array_equal(img, ref) and st.ray_segments == st_ref.ray_segments
+
+
 def test_shutdown_is_refused_while_a_scene_is_alive(ndev):
     """rt_shutdown used to delete the device contexts under live scenes; now it is a no-op with a message until the last
     scene is destroyed."""
