@@ -217,70 +217,33 @@ __device__ __forceinline__ float uniform_m1_1(Rng& r) { return u01(r) * 2.0f + -
 // c = center, rr = RN(r*r).  td = 2*d.  Returns true and t when a root lies in [t_min, t_max).
 __device__ __forceinline__ bool exact_sphere(V3 o, V3 td, V3 cen, float rr, float t_min, float t_max,
                                              float& t_out) {
-    V3 oc = o - cen;
-    float b = dot(td, oc);
-    float len = __builtin_sqrtf(dot(oc, oc));
-    float c = len * len - rr;
-    float disc = b * b - 4.0f * c;            // a1*a1 - _4*a2*a0, a2 = 1
-    if (disc < 0.0f) return false;
-    float x, y;
-    bool two;
-    if (disc == 0.0f) {
-        x = -b / 2.0f;
-        y = x;
-        two = false;
-    } else {
-        float sq = __builtin_sqrtf(disc);
-        float same_sign, diff_sign;
-        if (b < 0.0f) {
-            same_sign = -b + sq;
-            diff_sign = -b - sq;
-        } else {
-            same_sign = -b - sq;
-            diff_sign = -b + sq;
-        }
-        float x1, x2;
-        if (__builtin_fabsf(same_sign) > 2.0f) {
-            float a0x2 = 2.0f * c;
-            if (__builtin_fabsf(diff_sign) > 2.0f) {
-                x1 = a0x2 / same_sign;
-                x2 = a0x2 / diff_sign;
-            } else {
-                x1 = a0x2 / same_sign;
-                x2 = same_sign / 2.0f;
-            }
-        } else {
-            x1 = diff_sign / 2.0f;
-            x2 = same_sign / 2.0f;
-        }
-        if (x1 < x2) {
-            x = x1;
-            y = x2;
-        } else {
-            x = x2;
-            y = x1;
-        }
-        two = true;
-    }
-    bool xin = (x >= t_min) && (x < t_max);
-    if (!two) {
-        t_out = x;
-        return xin;
-    }
-    bool yin = (y >= t_min) && (y < t_max);
-    if (xin && yin) {
-        t_out = x < y ? x : y;
-        return true;
-    }
-    if (xin) {
-        t_out = x;
-        return true;
-    }
-    if (yin) {
-        t_out = y;
-        return true;
-    }
-    return false;
+    // Straight-line form: every lane computes both quotient roots and selects.  As nested branches (disc < 0, disc == 0,
+    // sign of b, the two "do not use the smallest divisor" tests, the ordering, the window cases) this was 8 branches and 13
+    // exec-mask regions per candidate — more scalar bookkeeping than arithmetic.  The values selected are
+    // exactly those of the nested form; a NaN discriminant (non-finite operands) fails every comparison below, as there.
+    const V3 oc = o - cen;
+    const float b = dot(td, oc);
+    const float len = __builtin_sqrtf(dot(oc, oc));
+    const float c = len * len - rr;
+    const float disc = b * b - 4.0f * c;            // a1*a1 - _4*a2*a0, a2 = 1
+    const float sq = __builtin_sqrtf(disc);         // (NaN for a negative discriminant: that lane reports a miss below)
+    const bool bneg = b < 0.0f;
+    const float same_sign = bneg ? -b + sq : -b - sq;
+    const float diff_sign = bneg ? -b - sq : -b + sq;
+    const float a0x2 = 2.0f * c;
+    const bool big_s = __builtin_fabsf(same_sign) > 2.0f, big_d = __builtin_fabsf(diff_sign) > 2.0f;
+    const float q1 = a0x2 / same_sign, q2 = a0x2 / diff_sign, hs = same_sign / 2.0f, hd = diff_sign / 2.0f;
+    const float x1 = big_s ? q1 : hd;
+    const float x2 = big_s ? (big_d ? q2 : hs) : hs;
+    const bool one = disc == 0.0f;                  // Roots::One([-a1 / (2 a2)])
+    const float r1 = -b / 2.0f;
+    const float x = one ? r1 : (x1 < x2 ? x1 : x2);
+    const float y = one ? r1 : (x1 < x2 ? x2 : x1);
+    const bool xin = (x >= t_min) && (x < t_max);
+    const bool yin = (y >= t_min) && (y < t_max);
+    // Two([x, y]): both in range -> the smaller, else the one in range; One([x]): x if in range (shapes/mod.rs:106-129)
+    t_out = (xin && yin) ? (x < y ? x : y) : (xin ? x : y);
+    return !(disc < 0.0f) && (xin || yin);
 }
 
 // mesh.rs:109-161 (two-sided Moller-Trumbore) -> Roots::One([dist]) -> shapes/mod.rs:109-115
