@@ -226,23 +226,15 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     const bool qnodes = traverse && sc->quant_ok && !(rq->flags & RT_FLAG_EXACT_NODES) &&
                         ((rq->flags & RT_FLAG_QUANT_NODES) || n_prims >= RT_QNODES_MIN_PRIMS);
     // LDS-resident tree (engine 4, kernel variant 3): the exact 64-byte nodes of a small scene staged into LDS by one
-    // 1024-thread workgroup per CU, 16-bit references / stack / leaf lists, materials and geometry alongside while they
-    // fit.  RT_FLAG_NO_LDS_TREE forces the L2-gather kernel (A/B runs, tests).
+    // 1024-thread workgroup per CU, 16-bit references / stack / leaf lists.  RT_FLAG_NO_LDS_TREE forces the
+    // L2-gather kernel (A/B runs, tests).
     static const bool ltree_env = [] { const char* e = getenv("RT_LDS_TREE"); return !e || atoi(e) != 0; }();
     bool ltree = false;
-    size_t lt_mat = 0, lt_emis = 0, lt_geom = 0;      // bytes staged besides the nodes (0 = stays in HBM)
     const size_t lt_lane = ((size_t)rtk::MAXL_LTREE + (size_t)(rq->max_bounces + 1) + (size_t)(sc->bvh_depth + 2)) * sizeof(uint16_t);
     if (traverse && !qnodes && ltree_env && !(rq->flags & RT_FLAG_NO_LDS_TREE) && sc->n_internal > 0 && n_prims <= 0x7fffu &&
         ((size_t)sc->n_internal + 1) * rtk::LNODE_DW < 0x8000u) {
         const size_t fixed = ((size_t)sc->n_internal + 1) * (rtk::LNODE_DW * 4) + lt_lane * rtk::LTREE_BLOCK;   // + the DONE node
-        if (fixed <= LDS_LIMIT) {
-            ltree = true;
-            static const int extras = [] { const char* e = getenv("RT_LDS_TREE_EXTRAS"); return e ? atoi(e) : 0; }();   // bit 0 mat, 1 emis, 2 geom (c3: no gain from any of them)
-            size_t used = fixed;
-            if ((extras & 1) && used + (size_t)n_prims * 16 <= LDS_LIMIT) { lt_mat = (size_t)n_prims * 16; used += lt_mat; }
-            if ((extras & 2) && used + (size_t)n_prims * 4 <= LDS_LIMIT) { lt_emis = (size_t)n_prims * 4; used += lt_emis; }
-            if ((extras & 4) && sc->n_sph && used + (size_t)sc->n_sph * 16 <= LDS_LIMIT) { lt_geom = (size_t)sc->n_sph * 16; used += lt_geom; }
-        }
+        ltree = fixed <= LDS_LIMIT;
     }
     const bool streamed = !traverse && sc->n_sph_pad > RESIDENT_MAX;
     p.chunk = traverse ? 0 : (streamed ? STREAM_CHUNK : sc->n_sph_pad);
@@ -296,14 +288,10 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     size_t lds = geom_bytes + cand_bytes + path_bytes + rr_bytes + stack_bytes;
     p.n_internal = sc->n_internal;
     p.lds_node_off = 0;
-    p.lds_mat_off = p.lds_emis_off = p.lds_geom_off = 0xffffffffu;
     const int bs = ltree ? rtk::LTREE_BLOCK : rtk::BLOCK;
     if (ltree) {
-        // [nodes][mat][geom][emis][leaf lists u16][path u16][stack u16]
+        // [nodes][leaf lists u16][path u16][stack u16]
         size_t off = (((size_t)sc->n_internal + 1) * (rtk::LNODE_DW * 4) + 15) & ~(size_t)15;
-        if (lt_mat) { p.lds_mat_off = (uint32_t)off; off += lt_mat; }
-        if (lt_geom) { p.lds_geom_off = (uint32_t)off; off += lt_geom; }
-        if (lt_emis) { p.lds_emis_off = (uint32_t)off; off += (lt_emis + 15) & ~(size_t)15; }
         p.lds_cand_off = (uint32_t)off;
         off += (size_t)rtk::MAXL_LTREE * bs * sizeof(uint16_t);
         p.lds_path_off = (uint32_t)off;

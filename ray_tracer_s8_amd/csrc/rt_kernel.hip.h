@@ -137,7 +137,6 @@ struct KParams {
     uint32_t refill_eighths;     // traversal: finished lanes are refilled once <= this many eighths of the live lanes still walk
     uint32_t n_internal;         // internal nodes of the tree (= TravNode count)
     uint32_t lds_node_off;       // LDS-resident tree (ISECT 5): byte offsets of the staged nodes ...
-    uint32_t lds_mat_off, lds_emis_off, lds_geom_off;   //   ... materials / emission / (cx,cy,cz,rr); 0xffffffff = stays in HBM
     const float4* bvh_nodes;     // [2*n_nodes]: (lo.xyz, parent as bits) (hi.xyz, -) — rt_bvh.h FlatNode
     const uint32_t* leaf_of;     // [n_sph+n_tri] primitive -> leaf node index (= DFS rank)
     unsigned long long* counters;// [0] segments [1] candidates [2] fallbacks
@@ -519,36 +518,9 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 3 ? R
                 q[18] = __uint_as_float((p.n_internal * (uint32_t)LNODE_DW) * 0x10001u);
             }
         }
-        const uint32_t np = p.n_sph + p.n_tri;
-        if (p.lds_mat_off != 0xffffffffu) {
-            float4* lm = reinterpret_cast<float4*>(lds_raw + p.lds_mat_off);
-            for (uint32_t i = tid; i < np; i += BLOCK) lm[i] = p.mat[i];
-        }
-        if (p.lds_emis_off != 0xffffffffu) {
-            float* le = reinterpret_cast<float*>(lds_raw + p.lds_emis_off);
-            for (uint32_t i = tid; i < np; i += BLOCK) le[i] = p.emis[i];
-        }
-        if (p.lds_geom_off != 0xffffffffu) {
-            float4* lg = reinterpret_cast<float4*>(lds_raw + p.lds_geom_off);
-            for (uint32_t i = tid; i < p.n_sph; i += BLOCK) lg[i] = p.geom[i];
-        }
         __syncthreads();
     }
     const float* const lnodes = reinterpret_cast<const float*>(lds_raw + p.lds_node_off);
-    // material / geometry fetch: LDS copy when the launch staged one, else HBM (L2)
-    auto mat_at = [&](uint32_t i) -> float4 {
-        if (LTREE && p.lds_mat_off != 0xffffffffu) return reinterpret_cast<const float4*>(lds_raw + p.lds_mat_off)[i];
-        return at32(p.mat, i);
-    };
-    auto emis_at = [&](uint32_t i) -> float {
-        if (LTREE && p.lds_emis_off != 0xffffffffu) return reinterpret_cast<const float*>(lds_raw + p.lds_emis_off)[i];
-        return at32(p.emis, i);
-    };
-    auto geom_at = [&](uint32_t i) -> float4 {
-        if (LTREE && p.lds_geom_off != 0xffffffffu) return reinterpret_cast<const float4*>(lds_raw + p.lds_geom_off)[i];
-        return at32(p.geom, i);
-    };
-
     const V3 corg = mk(p.org[0], p.org[1], p.org[2]);
     const V3 llc = mk(p.llc[0], p.llc[1], p.llc[2]);
     const V3 hor = mk(p.hor[0], p.hor[1], p.hor[2]);
@@ -861,7 +833,7 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 3 ? R
                     // lazily: only to a hit that would replace the running closest one.  (A lane without a finite
                     // inverse direction walked the exact nodes: nothing to validate.)
                     if (prim < p.n_sph) {
-                        const float4 g = geom_at(prim);
+                        const float4 g = at32(p.geom, prim);
                         if (exact_sphere(o, 2.0f * d, mk(g.x, g.y, g.z), g.w, p.t_min, p.t_max, t)) {   // (2f32 * ray.direction), sphere.rs:44
                             if (QNODES)
                                 consider_if(h, (int)prim, o, d, t, [&]() {
@@ -1248,8 +1220,8 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 3 ? R
             if (h.idx >= 0) {
                 WCOUNT(8);
                 LCOUNT(8);
-                const float em = emis_at((uint32_t)h.idx);
-                const float4 m = mat_at((uint32_t)h.idx);
+                const float em = at32(p.emis, (uint32_t)h.idx);
+                const float4 m = at32(p.mat, (uint32_t)h.idx);
                 if (em > 0.0f) {                              // main.rs:116-117
                     term_r = m.x * em;
                     term_g = m.y * em;
@@ -1258,7 +1230,7 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 3 ? R
                 } else {
                     V3 n;
                     if ((uint32_t)h.idx < p.n_sph) {
-                        float4 g = geom_at((uint32_t)h.idx);
+                        float4 g = at32(p.geom, (uint32_t)h.idx);
                         n = normalize_or_zero(h.p - mk(g.x, g.y, g.z));             // sphere.rs:49-51
                     } else {
                         const float* tv = p.tri + 9 * (size_t)(h.idx - p.n_sph);
@@ -1313,7 +1285,7 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 3 ? R
                     LCOUNT(11);
                     uint32_t idx = p.path32 ? reinterpret_cast<uint32_t*>(lpath)[i * BLOCK + tid]
                                             : (uint32_t) reinterpret_cast<uint16_t*>(lpath)[i * BLOCK + tid16];
-                    float4 m = mat_at((uint32_t)idx);
+                    float4 m = at32(p.mat, (uint32_t)idx);
                     term_r = m.x * term_r;
                     term_g = m.y * term_g;
                     term_b = m.z * term_b;

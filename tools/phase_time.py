@@ -15,18 +15,38 @@ for k in range(rq.divisions):
     r = rq.copy(); r.division_no = k; r.flags = int(sys.argv[2]) if len(sys.argv) > 2 else 0; reqs.append(r)
 names = ["pixel acquisition", "ray generation", "traversal steps (+ inline flushes)", "root tests (flush)",
          "shade + finish + store", "loop top / counter drain", "-", "-"]
+hip = C.CDLL("libamdhip64.so")
+nb = (rq.height // rq.divisions) * rq.width * 3
 with rt.Scene(0, rt.World(sph)) as sc:
-    sc.render_tiles(reqs)
+    dbuf = C.c_void_p()
+    assert hip.hipMalloc(C.byref(dbuf), C.c_size_t(nb * len(reqs))) == 0
+    ptrs = [dbuf.value + i * nb for i in range(len(reqs))]
+    sc.render_tiles_device(reqs, ptrs, nb)               # ONE launch per frame (the host-buffer path splits it in two)
+    hip.hipDeviceSynchronize()
+    sc.collect()
+    sc.render_tiles(reqs[:1])
     lib = _abi.load()
     lib.rt_debug_read_counters.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
     zero = (C.c_ulonglong * 8)()
-    outs, _, st = sc.render_tiles(reqs)
+    zero8 = None
+    lib.rt_debug_read_counters(sc._h, 4 + 8192 + 160, 8, zero)       # (counters so far: warm-up launches)
+    base = list(zero)
+    sc.render_tiles_device(reqs, ptrs, nb)
+    hip.hipDeviceSynchronize()
+    st = sc.collect()
     buf = (C.c_ulonglong * 8)()
     lib.rt_debug_read_counters(sc._h, 4 + 8192 + 160, 8, buf)
+    for i in range(8):
+        buf[i] -= base[i]
     tot = sum(buf)
-    print(f"segments {st.ray_segments}  kernel {st.kernel_ms:.2f} ms (two frames accumulated in the clock)  wave cycles {tot:.3e}")
+    print(f"segments {st.ray_segments}  kernel {st.kernel_ms:.2f} ms (one launch)  wave cycles {tot:.3e}")
     for i, n in enumerate(names):
         if buf[i]:
             print(f"  {n:36s} {100.0 * buf[i] / tot:6.2f} %")
+    ex = (C.c_ulonglong * 5)()
+    lib.rt_debug_read_counters(sc._h, 4 + 8192 + 168, 5, ex)
+    nw = 256 * 16 if st.engine == 4 else None
+    if nw:
+        print(f"  longest wave (all launches so far) {ex[0]:.3e} cycles, mean of this launch {tot / nw:.3e}: mean / longest = {tot / nw / max(ex[0], 1):.3f}")
 os.environ["RT_EXTRA_HIPCC_FLAGS"] = ""
 build.build(force=True)
