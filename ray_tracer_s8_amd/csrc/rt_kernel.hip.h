@@ -890,27 +890,37 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 3 ? R
             const uint32_t DONE = p.n_internal * (uint32_t)LNODE_DW;            // node references are offsets in dwords
             constexpr int STEPS = RT_STEPS_PER_CHECK_LTREE;
             static_assert(MAXL_LTREE > STEPS, "the leaf list must take a block of appends");
+            // Inside a block the stack pointer and the list length are carried as LDS byte addresses (top_a: the lane's top
+            // stack slot; cnt_m: one slot below the lane's next list slot), so that the three accesses of a step are a
+            // register plus an immediate offset: no index arithmetic in the step.
+            constexpr uint32_t SLOT = (uint32_t)BLOCK * 2u;      // bytes between two slots of a lane's column
+            typedef __attribute__((address_space(3))) unsigned char lds_byte;
+            typedef __attribute__((address_space(3))) uint16_t lds_u16;
+            const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_byte*)lds_raw;               // LDS address of the dynamic area
+            const uint32_t stack0_a = lds0 + p.lds_stack_off + (uint32_t)tid16 * 2u;     // slot 0 (DONE) of this lane
+            const uint32_t list0_m = lds0 + p.lds_cand_off + (uint32_t)tid16 * 2u - SLOT; // one slot below list slot 0
+            uint32_t top_a = 0, cnt_m = 0;
+            auto lds16 = [&](uint32_t a) -> lds_u16& { return *(lds_u16*)(uintptr_t)a; };
             auto step = [&](auto slow_tag) {
                 constexpr bool SLOW = decltype(slow_tag)::value;
                 const bool is_leaf = t_ref > 0x7fffu;
                 const uint32_t ni = is_leaf ? DONE : t_ref;
                 if (STATS) n_int += (ni != DONE) ? 1u : 0u;
-                const uint32_t top = (uint32_t)lstack16[(t_sp - 1u) * BLOCK + tid16];
+                const uint32_t top = (uint32_t)lds16(top_a);
                 WCOUNT(5);
                 LCOUNT(5);
-                uint16_t* const dst = is_leaf ? &lc16[t_cnt * BLOCK + tid16] : &lstack16[t_sp * BLOCK + tid16];
-                *dst = (uint16_t)t_ref;                          // (the flush masks the leaf flag off)
+                // a leaf goes to the next list slot, anything else to the free stack slot (overwritten by the push below)
+                lds16((is_leaf ? cnt_m : top_a) + SLOT) = (uint16_t)t_ref;       // (the flush masks the leaf flag off)
                 // Ray::intersects_aabb (ray.rs:174-194) on both child boxes; (near, far) planes fetched by sign
                 const float* __restrict__ nd = lnodes + ni;
                 const float* __restrict__ fx = nd + sgx;
                 const float* __restrict__ fy = nd + 6 + sgy;
                 const float* __restrict__ fz = nd + 12 + sgz;
-                float p0 = fx[0], p1 = fx[1], p2 = fx[3], p3 = fx[4], p4 = fy[0], p5 = fy[1], p6 = fy[3], p7 = fy[4];
-                float p8 = fz[0], p9 = fz[1], p10 = fz[3], p11 = fz[4];
-                uint32_t refs = __float_as_uint(nd[18]);
+                const float p0 = fx[0], p1 = fx[1], p2 = fx[3], p3 = fx[4], p4 = fy[0], p5 = fy[1], p6 = fy[3], p7 = fy[4];
+                const float p8 = fz[0], p9 = fz[1], p10 = fz[3], p11 = fz[4];
+                const uint32_t refs = __float_as_uint(nd[18]);
                 // all seven reads in flight before the first use (the scheduler, short of registers, serialised them)
-                asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7), "+v"(p8),
-                             "+v"(p9), "+v"(p10), "+v"(p11), "+v"(refs));
+                __builtin_amdgcn_sched_barrier(0);
                 const float lxn = (p0 - o.x) * aux.inv.x, lxf = (p1 - o.x) * aux.inv.x;
                 const float rxn = (p2 - o.x) * aux.inv.x, rxf = (p3 - o.x) * aux.inv.x;
                 const float lyn = (p4 - o.y) * aux.inv.y, lyf = (p5 - o.y) * aux.inv.y;
@@ -927,11 +937,11 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 3 ? R
                     hr = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(rxn, ryn), rzn), 0.0f) <= __builtin_fminf(__builtin_fminf(rxf, ryf), rzf);
                 }
                 const uint32_t cl = refs & 0xffffu, cr = refs >> 16;
-                lstack16[t_sp * BLOCK + tid16] = (uint16_t)cr;     // right subtree after the whole left subtree
+                lds16(top_a + SLOT) = (uint16_t)cr;                // right subtree after the whole left subtree
                 const bool any = hl || hr;
                 t_ref = any ? (hl ? cl : cr) : top;
-                t_sp = max(t_sp + ((hl && hr) ? 1u : 0u) - (any ? 0u : 1u), 1u);
-                t_cnt += is_leaf ? 1u : 0u;
+                top_a = max(top_a + ((hl && hr) ? SLOT : 0u) - (any ? 0u : SLOT), stack0_a);
+                cnt_m += is_leaf ? SLOT : 0u;
             };
             for (;;) {
                 const uint32_t walking = (uint32_t)__builtin_popcountll(__ballot(in_trav));
@@ -940,6 +950,8 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 3 ? R
                 if (in_trav && t_cnt > (uint32_t)(MAXL_LTREE - STEPS)) flush();   // room for a block of appends
                 const bool slow = __ballot(in_trav && !aux.finite) != 0;         // wave-uniform
                 if (in_trav) {
+                    top_a = stack0_a + (t_sp - 1u) * SLOT;
+                    cnt_m = list0_m + t_cnt * SLOT;
                     if (slow) {
 #pragma unroll
                         for (int rep = 0; rep < STEPS; rep++) step(std::true_type{});
@@ -947,6 +959,8 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 3 ? R
 #pragma unroll
                         for (int rep = 0; rep < STEPS; rep++) step(std::false_type{});
                     }
+                    t_sp = (top_a - stack0_a) / SLOT + 1u;
+                    t_cnt = (cnt_m - list0_m) / SLOT;
                     in_trav = t_ref != DONE;
                 }
             }
@@ -1304,7 +1318,7 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 3 ? R
                     float b = __builtin_sqrtf(sum_b / p.spp_f);
                     const uint32_t pslot = strip >> 8, sidx = strip & 0xffu;
                     size_t oidx = ((size_t)(pyg - p.strips[sidx].y0) * p.W + px) * 3;      // row within the strip
-                    if (pslot == STAGE_DIRECT) {
+                    if (!CAN_STAGE || pslot == STAGE_DIRECT) {
                         uint8_t* orgb = p.strips[sidx].rgb;
                         orgb[oidx + 0] = f32_as_u8(r * 255.999f);
                         orgb[oidx + 1] = f32_as_u8(g * 255.999f);
