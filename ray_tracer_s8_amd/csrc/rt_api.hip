@@ -333,8 +333,7 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
         // refill threshold: long walks (large scenes) want finished lanes replaced sooner, short walks amortise the
         // per-round shading / ray-generation code over more finished lanes (tools/variants_q.sh sweeps)
         static const int forced = [] { const char* e = getenv("RT_REFILL_EIGHTHS"); return e ? atoi(e) : 0; }();
-        // (the LDS-tree kernel's steps are cheap against its per-round shading code: it refills latest, 1/8)
-        p.refill_eighths = forced > 0 ? (uint32_t)forced : (ltree ? 1u : n_prims >= RT_QNODES_MIN_PRIMS ? 4u : 2u);
+        p.refill_eighths = forced > 0 ? (uint32_t)forced : (n_prims >= RT_QNODES_MIN_PRIMS ? 4u : 2u);
     }
     p.leaf_of = sc->d_leaf_of;
     p.n_strips = n;

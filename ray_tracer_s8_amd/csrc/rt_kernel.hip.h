@@ -62,8 +62,8 @@ constexpr int TRAV_STACK = 64;   // traversal stack entries per lane (host falls
 #ifndef RT_STEPS_PER_CHECK
 #define RT_STEPS_PER_CHECK 8
 #endif
-#ifndef RT_STEPS_PER_CHECK_LTREE   // LDS-tree kernel: steps per block of its branch-free walk (tools/sweep_steps.sh: 6 at refill 1/8)
-#define RT_STEPS_PER_CHECK_LTREE 6
+#ifndef RT_STEPS_PER_CHECK_LTREE   // LDS-tree kernel: steps per block of its branch-free walk (tools/sweep_steps.sh: 8 at refill 2/8)
+#define RT_STEPS_PER_CHECK_LTREE 8
 #endif
 #ifndef RT_STEPS_PER_CHECK_Q    // quantised-node kernel (large scenes, long walks): c5 +1 % over 8
 #define RT_STEPS_PER_CHECK_Q 16
