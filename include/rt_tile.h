@@ -96,13 +96,13 @@ enum {
     /* Walk the whole root-to-leaf AABB chain when validating a hit instead of using the
      * leaf-box monotonicity shortcut (A/B testing; identical images). */
     RT_FLAG_FULL_CHAIN = 1u << 3,
-    /* Closest-hit engine.  Default: linear scan over the LDS-resident primitive list for scenes up to 48
+    /* Closest-hit engine.  Default: linear scan over the LDS-resident primitive list for scenes up to 32
      * spheres (and no mesh), per-lane traversal of the reference BVH above that.  Both give the
      * reference's result bit for bit; these force one or the other (A/B runs, tests). */
     RT_FLAG_BVH_TRAVERSE = 1u << 4,
     RT_FLAG_LINEAR_SCAN = 1u << 5,
-    /* Traversal node format.  Default: the exact 64-byte nodes below 4096 primitives, the
-     * 32-byte conservatively quantised nodes (exact validation at the leaves) from there up.  Identical images;
+    /* Traversal node format.  Default: the exact 64-byte nodes below 4096 primitives and for meshes, the
+     * 32-byte conservatively quantised nodes (exact validation at the leaves) for larger sphere scenes.  Identical images;
      * these force one or the other (A/B runs, tests). */
     RT_FLAG_EXACT_NODES = 1u << 6,
     RT_FLAG_QUANT_NODES = 1u << 7,

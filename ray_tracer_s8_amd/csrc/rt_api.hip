@@ -86,7 +86,7 @@ constexpr uint32_t STREAM_CHUNK = 2048;         // chunk size when streaming thr
 constexpr uint32_t STACK_LDS_MAX = 12;          // quantised-node kernel: stack entries per lane in LDS, deeper ones in HBM
 constexpr uint32_t TRAVERSE_MIN_TRIS = 4;       // ... or above this many triangles (tools/crossover_tris.py: the LDS-tree walk wins from 8 triangles up)
 constexpr uint32_t RT_QNODES_MIN_PRIMS = 4096;   // from here up the traversal walks the 32-byte quantised nodes (tools/crossover_q.py)
-constexpr uint32_t TRAVERSE_MIN_PRIMS = 48;     // above this many primitives the BVH-traversal engine is the default (measured crossover with the LDS-resident tree, tools/crossover.py: 0.91 at 16, 1.03 at 32, 1.10 at 64, 2.0 at 512)
+constexpr uint32_t TRAVERSE_MIN_PRIMS = 32;     // above this many primitives the BVH-traversal engine is the default (measured with the LDS-resident tree: tools/crossover.py 0.91 at 16, 1.03 at 32, 1.10 at 64, 2.0 at 512; tools/heuristics_matrix.py at 48: +15...20 % on sparse fields, sheets and clusters, -3 % on dense overlap)
 
 }  // namespace
 
@@ -223,8 +223,10 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     // LDS plan that keeps five workgroups per CU whatever the tree's depth): +14 % on sparse fields of every size, +17...29 %
     // on dense fields of 32 768+ spheres, within 2.5 % either way in between; below it the exact-node kernel's six
     // waves per SIMD win on the headline scene (c3 +1.5 %).  tools/crossover_q.py, DESIGN.md 4.7
+    // (meshes keep the exact nodes: a quantised walk validates a triangle leaf by walking its box chain — two more gathers
+    // per improving hit — and lost 2...16 % on the generated terrains of 7 200 and 100 352 triangles, tools/heuristics_matrix.py)
     const bool qnodes = traverse && sc->quant_ok && !(rq->flags & RT_FLAG_EXACT_NODES) &&
-                        ((rq->flags & RT_FLAG_QUANT_NODES) || n_prims >= RT_QNODES_MIN_PRIMS);
+                        ((rq->flags & RT_FLAG_QUANT_NODES) || (n_prims >= RT_QNODES_MIN_PRIMS && sc->n_tri <= sc->n_sph));
     // LDS-resident tree (engine 4, kernel variant 3): the exact 64-byte nodes of a small scene staged into LDS by one
     // 1024-thread workgroup per CU, 16-bit references / stack / leaf lists.  RT_FLAG_NO_LDS_TREE forces the
     // L2-gather kernel (A/B runs, tests).
