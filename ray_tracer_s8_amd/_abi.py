@@ -10,6 +10,8 @@ import numpy as np
 
 from . import build as _build
 
+RT_ABI_VERSION = 2          # include/rt_tile.h RT_ABI_VERSION; load() refuses a library of another version
+
 # ---- status codes (rt_status)
 RT_OK = 0
 RT_ERR_BAD_ARG = -1
@@ -125,6 +127,9 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     lib.rt_shutdown.restype = None
     lib.rt_abi_version.argtypes = []
     lib.rt_abi_version.restype = C.c_uint32
+    if lib.rt_abi_version() != RT_ABI_VERSION:
+        raise RuntimeError(f"{path} has ABI version {lib.rt_abi_version()}, this binding is written for "
+                           f"{RT_ABI_VERSION}: rebuild it (python -m ray_tracer_s8_amd.build)")
     lib.rt_strerror.argtypes = [C.c_int]
     lib.rt_strerror.restype = C.c_char_p
     lib.rt_last_error.argtypes = []

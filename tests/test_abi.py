@@ -30,7 +30,15 @@ def test_library_exports_every_declared_symbol():
     lib = _abi.load()
     for name in declared_functions():
         assert hasattr(lib, name), f"{name} declared in rt_tile.h but not exported by librt_s8.so"
-    assert lib.rt_abi_version() == 2
+    assert lib.rt_abi_version() == 2 == _abi.RT_ABI_VERSION
+
+
+def test_abi_version_is_one_number_everywhere():
+    # header, binding and the driver's build check must agree (build() once asserted a stale literal)
+    m = re.search(r"#define\s+RT_ABI_VERSION\s+(\d+)u", HEADER)
+    assert m and int(m.group(1)) == _abi.RT_ABI_VERSION
+    entry = (Path(__file__).resolve().parents[1] / "__graft_entry__.py").read_text()
+    assert "rt_abi_version() == _abi.RT_ABI_VERSION" in entry
 
 
 def test_header_cites_reference_lines():
