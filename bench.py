@@ -366,6 +366,24 @@ def main():
             },
             "roofline_linear": linear,
         }
+        if st.engine in (2, 3):
+            # The L2-gather walks are bound by their node gathers, not by flops: beside the FP32 object, the
+            # node records fetched per second against the chip's rate for fully divergent gathers of that record size,
+            # measured by tools/ubench/gather_rate.hip (committed: profiles/r02_gather_rate.json).  Lanes that share a line
+            # are cheaper than the microbenchmark's, so this fraction is an estimate and is not asserted <= 1.
+            try:
+                gr = json.loads((ROOT / "profiles" / "r02_gather_rate.json").read_text())
+                key, nbytes, ngath = ("64B_4_gathers", 64, 4) if st.engine == 2 else ("32B_2_gathers", 32, 2)
+                peak_rec = gr["lane_records_per_cycle_per_cu"][key]["64_lanes"] * gr["cus"] * gr["clock_mhz"] * 1e6
+                ach_rec = census["node_steps"] * scale / avg_launch_s
+                line["roofline_gather"] = {
+                    "bound": "divergent gathers (texture-address / L1 path)", "unit": "G node records/s",
+                    "achieved": ach_rec / 1e9, "peak": peak_rec / 1e9, "frac": ach_rec / peak_rec,
+                    "record_bytes": nbytes, "gather_instructions_per_record": ngath,
+                    "peak_source": "committed microbenchmark profiles/r02_gather_rate.json (tools/ubench/gather_rate.hip: every "
+                                   "lane on its own line, 2 MiB table, 5 waves per SIMD), not measured in this run"}
+            except Exception as e:                       # the file is part of the repo; a bench line without it still stands
+                line["roofline_gather"] = {"error": repr(e)}
         assert 0.0 < line["roofline"]["frac"] <= 1.0, line["roofline"]
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_scale)

@@ -1009,6 +1009,21 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 3 ? R
                             asm volatile("" : "+v"(qb.x), "+v"(qb.y), "+v"(qb.z), "+v"(qb.w));   // keep the two 16-byte loads whole
                             cl = qb.z;
                             cr = qb.w;
+#ifdef RT_PROBE_EXTRA_GATHER
+                            // timing probe (never in a product build; tools/ab.sh): RT_PROBE_EXTRA_GATHER more
+                            // 16-byte gathers per node step, n > 0: the same node again (same line), n < 0: another node's line
+                            {
+                                uint32_t zero = 0;
+                                asm volatile("" : "+v"(zero));
+                                for (int e = 0; e < (RT_PROBE_EXTRA_GATHER > 0 ? RT_PROBE_EXTRA_GATHER : -RT_PROBE_EXTRA_GATHER); e++) {
+                                    const uint32_t other = RT_PROBE_EXTRA_GATHER > 0 ? t_ref : ((t_ref + 1u + e) * 2654435761u) % p.n_internal;
+                                    const uint4* nx = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.travq) + (other << 5));
+                                    asm volatile("" : "+v"(nx));
+                                    uint4 qx = nx[0];
+                                    cl ^= qx.x & zero;
+                                }
+                            }
+#endif
                             if (qfin) {
                                 // slab test in grid units: t = fma(q, ig, cq), the same real value as
                                 // ((base + q*step) - o) * inv up to < 0.15 grid unit of rounding; the boxes carry >= 1 grid
