@@ -307,7 +307,8 @@ def main():
         eng_names = ["linear scan, scene resident in LDS", "linear scan, scene streamed through LDS",
                      "per-lane traversal of the reference BVH (exact nodes gathered from L2)",
                      "per-lane traversal of the reference BVH (quantised nodes, exact leaf validation)",
-                     "per-lane traversal of the reference BVH (exact nodes resident in LDS)"]
+                     "per-lane traversal of the reference BVH (exact nodes resident in LDS)",
+                     "per-lane traversal of the reference BVH (quantised nodes, nearer child first, distance culling, exact leaf validation)"]
         line = {
             "metric": "Mrays/sec @ 4K/8spp 1024-sphere" if args.workload == "c3" else f"Mrays/sec @ {args.workload}",
             "value": segs / elapsed / 1e6,
@@ -366,7 +367,7 @@ def main():
             },
             "roofline_linear": linear,
         }
-        if st.engine in (2, 3):
+        if st.engine in (2, 3, 5):
             # The L2-gather walks are bound by their node gathers, not by flops: beside the FP32 object, the
             # node records fetched per second against the chip's rate for fully divergent gathers of that record size,
             # measured by tools/ubench/gather_rate.hip (committed: profiles/r02_gather_rate.json).  Lanes that share a line

@@ -111,7 +111,12 @@ enum {
     RT_FLAG_NO_LDS_TREE = 1u << 8,
     /* Measurement aid (bench.py's roofline object): run the traversal kernel's counting twin, which also counts the
      * internal BVH nodes visited (rt_tile_stats.node_steps).  Same image; a few per cent slower, never the timed launch. */
-    RT_FLAG_COUNT_STEPS = 1u << 9
+    RT_FLAG_COUNT_STEPS = 1u << 9,
+    /* Quantised walk, nearer child first, skipping every subtree whose box the ray enters beyond the running closest hit by
+     * more than a proven slack (scenes of spheres only; identical images).  Default for sphere scenes on the quantised
+     * nodes that are dense enough for it to pay (c5 and denser); these force it on / off (A/B runs, tests). */
+    RT_FLAG_CULL_WALK = 1u << 10,
+    RT_FLAG_NO_CULL_WALK = 1u << 11
 };
 
 typedef struct rt_tile_request {
@@ -149,7 +154,8 @@ typedef struct rt_tile_stats {
     uint32_t engine;            /* closest-hit engine of the last launch: 0 linear scan (scene resident
                                    in LDS), 1 linear scan (scene streamed through LDS), 2 BVH traversal (exact nodes),
                                    3 BVH traversal (quantised nodes + exact leaf validation),
-                                   4 BVH traversal, exact nodes resident in LDS */
+                                   4 BVH traversal, exact nodes resident in LDS,
+                                   5 BVH traversal, quantised nodes, nearer child first with distance culling */
     uint32_t broad_form;        /* linear engines: 0 = oc form, 1 = expanded form   */
     uint64_t node_steps;        /* traversal engines under RT_FLAG_COUNT_STEPS: internal BVH nodes visited
                                    (each = two child-box slab tests); 0 otherwise.  broad_candidates = leaves

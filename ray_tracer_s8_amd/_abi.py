@@ -35,6 +35,8 @@ RT_FLAG_EXACT_NODES = 64
 RT_FLAG_QUANT_NODES = 128
 RT_FLAG_NO_LDS_TREE = 256
 RT_FLAG_COUNT_STEPS = 512
+RT_FLAG_CULL_WALK = 1024
+RT_FLAG_NO_CULL_WALK = 2048
 RT_MAX_BOUNCES = 62
 
 # numpy dtypes with the exact layout of rt_sphere / rt_triangle (no padding)

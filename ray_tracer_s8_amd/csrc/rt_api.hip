@@ -109,6 +109,10 @@ struct rt_scene {
                                        // launches are chained even when the caller spreads them over several streams
     uint4* d_travq = nullptr;      // rtbvh::QNode[] (quantised twin)
     float4* d_geom_r = nullptr;    // (cx,cy,cz,radius)
+    uint32_t* d_big = nullptr;     // culled walk: spheres root-tested at query start (too large for its slack)
+    uint32_t n_big = 0;
+    float r_slack = 0.f;           //   largest radius among the other spheres
+    bool cull_pays = false;        //   host heuristic: the scene is dense enough for the culled walk (build_host_scene)
     rtbvh::QGrid grid;
     float leaf_density = 0.f;      // sum of primitive box areas / scene box area (node-format heuristic)
     bool quant_ok = false;         // quantised walk usable and worthwhile (grid step small against the primitives)
@@ -238,6 +242,14 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
         const size_t fixed = ((size_t)sc->n_internal + 1) * (rtk::LNODE_DW * 4) + lt_lane * rtk::LTREE_BLOCK;   // + the DONE node
         ltree = fixed <= LDS_LIMIT;
     }
+    // Culled walk (engine 5, kernel variant 5): the quantised walk nearer child first, subtrees beyond the running closest hit
+    // skipped.  Spheres only (the bound is derived from the sphere root test's error terms).
+    // Default where the host heuristic says it pays (cull_pays: DESIGN.md 4.7); RT_FLAG_CULL_WALK / RT_FLAG_NO_CULL_WALK
+    // force it on / off (A/B runs, tests), RT_CULL_WALK=0/1 likewise for a whole process.
+    static const int cull_env = [] { const char* e = getenv("RT_CULL_WALK"); return e ? atoi(e) : -1; }();
+    const bool cull_want = cull_env >= 0 ? cull_env != 0
+                           : (rq->flags & RT_FLAG_NO_CULL_WALK) ? false : ((rq->flags & RT_FLAG_CULL_WALK) != 0 || sc->cull_pays);
+    const bool cull = qnodes && cull_want && sc->n_tri == 0 && std::isfinite(sc->r_slack);
     const bool streamed = !traverse && sc->n_sph_pad > RESIDENT_MAX;
     p.chunk = traverse ? 0 : (streamed ? STREAM_CHUNK : sc->n_sph_pad);
     p.n_chunks = p.chunk ? (sc->n_sph_pad + p.chunk - 1) / p.chunk : 0;
@@ -364,13 +376,17 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     // persistent grid: as many workgroups as the chip holds at this LDS/VGPR budget
     int per_cu = 0;
     const bool count_steps = traverse && (rq->flags & RT_FLAG_COUNT_STEPS);
-    const rtk::KernelFn kern = traverse ? rtk::kernel_traverse(ltree ? 3 : qnodes ? (capped ? 2 : 1) : 0, count_steps) : rtk::kernel_linear(streamed, expanded);
+    const bool cull_run = cull && !capped;            // (a tree too deep for the LDS stack keeps the capped-stack kernel)
+    p.big = sc->d_big;
+    p.n_big = sc->n_big;
+    p.r_slack = sc->r_slack;
+    const rtk::KernelFn kern = traverse ? rtk::kernel_traverse(ltree ? 3 : qnodes ? (capped ? 2 : cull_run ? 5 : 1) : 0, count_steps) : rtk::kernel_linear(streamed, expanded);
     HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, bs, lds));
     if (per_cu < 1) per_cu = 1;
     static const bool verbose = getenv("RT_VERBOSE") != nullptr;
     if (verbose)
         fprintf(stderr, "[rt] engine %d%s  lds %zu B  workgroups/CU %d  leaf slots %u  bvh depth %u  leaf density %.3f  prims %u\n",
-                traverse ? (ltree ? 4 : qnodes ? 3 : 2) : (streamed ? 1 : 0), capped ? " (capped stack)" : "", lds, per_cu, maxl,
+                traverse ? (ltree ? 4 : qnodes ? (cull_run ? 5 : 3) : 2) : (streamed ? 1 : 0), capped ? " (capped stack)" : "", lds, per_cu, maxl,
                 sc->bvh_depth, sc->leaf_density, n_prims);
     uint32_t blocks = (uint32_t)sc->ctx->n_cu * (uint32_t)per_cu;
     const uint32_t waves_per_wg = (uint32_t)bs / 64u;
@@ -402,7 +418,7 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     }
     HIPCHK(hipMemsetAsync(p.queue, 0, sizeof(unsigned long long), stream));
     HIPCHK(hipEventRecord(ev.a, stream));
-    sc->last_engine = traverse ? (ltree ? 4u : qnodes ? 3u : 2u) : (streamed ? 1u : 0u);
+    sc->last_engine = traverse ? (ltree ? 4u : qnodes ? (cull_run ? 5u : 3u) : 2u) : (streamed ? 1u : 0u);
     sc->last_form = expanded ? 1u : 0u;
     hipLaunchKernelGGL(kern, grid, block, lds, stream, p);
     HIPCHK(hipGetLastError());
@@ -530,7 +546,7 @@ static int ensure_ctx(DeviceCtx* c) {
         for (int expanded = 0; expanded < 2; expanded++)
             HIPCHK(hipFuncSetAttribute((const void*)rtk::kernel_linear(streamed != 0, expanded != 0),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
-    for (int variant = 0; variant < 4; variant++)
+    for (int variant = 0; variant < 6; variant++)
         for (int stats = 0; stats < 2; stats++)
             HIPCHK(hipFuncSetAttribute((const void*)rtk::kernel_traverse(variant, stats != 0),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
@@ -569,6 +585,11 @@ struct HostScene {
     float leaf_density = 0.f, bvh_build_ms = 0.f;
     uint32_t n_internal = 0;         // internal nodes of the tree (bvh.trav may carry one placeholder)
     rtbvh::FlatBVH bvh;
+    std::vector<uint32_t> big;       // culled walk: spheres far larger than the rest, and ...
+    uint32_t n_big = 0;
+    float r_slack = 0.f;             // ... the largest radius among the others
+    bool cull_pays = false;          // enough of the rays hit something for nearer-first + culling to beat the plain walk
+    float cull_density = 0.f;        // sum of the other spheres' box areas / area of the box around them
 };
 
 static int check_world(const rt_sphere* sp, uint32_t ns, const rt_triangle* tr, uint32_t nt) {
@@ -718,6 +739,52 @@ static void build_host_scene(const rt_sphere* sp, uint32_t ns, const rt_triangle
     }
     hs.geom_r.assign(ns ? ns : 1, make_float4(0.f, 0.f, 0.f, 0.f));
     for (uint32_t i = 0; i < ns; i++) hs.geom_r[i] = make_float4(sp[i].cx, sp[i].cy, sp[i].cz, sp[i].radius);
+    // culled walk: its distance bound carries sqrt(2) * (largest radius) of slack, so the few spheres far larger than the
+    // rest (a ground sphere) are listed apart and root-tested at every query start instead
+    {
+        std::vector<float> rad(ns);
+        for (uint32_t i = 0; i < ns; i++) rad[i] = fabsf(sp[i].radius);
+        float med = 0.f;
+        if (ns) {
+            std::vector<float> tmp(rad);
+            std::nth_element(tmp.begin(), tmp.begin() + ns / 2, tmp.end());
+            med = tmp[ns / 2];
+        }
+        std::vector<uint32_t> cand;
+        for (uint32_t i = 0; i < ns; i++)
+            if (rad[i] > 8.0f * med) cand.push_back(i);
+        std::sort(cand.begin(), cand.end(), [&](uint32_t a, uint32_t b) { return rad[a] > rad[b] || (rad[a] == rad[b] && a < b); });
+        if (cand.size() > 16) cand.resize(16);
+        std::vector<char> is_big(ns ? ns : 1, 0);
+        for (uint32_t i : cand) is_big[i] = 1;
+        float rs = 0.f;
+        for (uint32_t i = 0; i < ns; i++)
+            if (!is_big[i] && rad[i] > rs) rs = rad[i];
+        hs.big = cand;
+        hs.n_big = (uint32_t)cand.size();
+        hs.r_slack = rs;
+        if (hs.big.empty()) hs.big.push_back(0);
+        // Does it pay?  The ratio below is the expected number of (non-big) primitive boxes a random line through their
+        // common box meets (Cauchy: box areas add up).  tools/cull_matrix.py, 2560x1440: sparse fields at 0.06...0.35 lose
+        // 5...7 % to the ordering and the early root tests, c5 at 0.95 gains 12 %, fields / mixed radii / dense overlap at
+        // 2...30 gain 1.35...3.5 x.  And the bound's slack (1.5 r_slack) must be small against the scene.
+        double area = 0.0;
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (uint32_t i = 0; i < ns; i++) {
+            if (is_big[i]) continue;
+            const double e = 2.0 * rad[i];
+            area += 3.0 * e * e;
+            const float c[3] = {sp[i].cx, sp[i].cy, sp[i].cz};
+            for (int a3 = 0; a3 < 3; a3++) {
+                lo[a3] = fminf(lo[a3], c[a3] - rad[i]);
+                hi[a3] = fmaxf(hi[a3], c[a3] + rad[i]);
+            }
+        }
+        const double ex = (double)hi[0] - lo[0], ey = (double)hi[1] - lo[1], ez = (double)hi[2] - lo[2];
+        const double root = ex * ey + ey * ez + ez * ex, diag = std::sqrt(ex * ex + ey * ey + ez * ez);
+        hs.cull_density = root > 0.0 ? (float)(area / root) : 0.f;
+        hs.cull_pays = nt == 0 && root > 0.0 && std::isfinite(area / root) && area / root >= 0.7 && (double)rs <= 0.05 * diag;
+    }
 }
 
 // HostScene -> device: allocate, upload on the device's stream, hand back the handle
@@ -788,6 +855,10 @@ static int upload_scene(int device, const HostScene& hs, rt_scene** out) {
     SC_UP(d_trav, bvh.trav);
     SC_UP(d_travq, bvh.travq);
     SC_UP(d_geom_r, hs.geom_r);
+    SC_UP(d_big, hs.big);
+    sc->n_big = hs.n_big;
+    sc->r_slack = hs.r_slack;
+    sc->cull_pays = hs.cull_pays;
     SC_CHK(hipMalloc(&sc->d_counters, COUNTER_WORDS * sizeof(unsigned long long)));
     SC_CHK(hipMemsetAsync(sc->d_counters, 0, COUNTER_WORDS * sizeof(unsigned long long), ctx->stream));
     SC_CHK(hipEventRecord(e1, ctx->stream));
@@ -798,8 +869,8 @@ static int upload_scene(int device, const HostScene& hs, rt_scene** out) {
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     if (getenv("RT_VERBOSE"))
-        fprintf(stderr, "[rt] scene: %u prims  bvh build %.2f ms (host)  uploads %.2f ms  upload total %.2f ms\n",
-                hs.ns + hs.nt, sc->bvh_build_ms, sc->h2d_ms,
+        fprintf(stderr, "[rt] scene: %u prims  culled walk: %u big spheres, slack radius %g, box density %.3f -> %s  bvh build %.2f ms (host)  uploads %.2f ms  upload total %.2f ms\n",
+                hs.ns + hs.nt, hs.n_big, hs.r_slack, hs.cull_density, hs.cull_pays ? "default" : "off", sc->bvh_build_ms, sc->h2d_ms,
                 std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_create0).count());
     guard.sc = nullptr;
     *out = sc;
@@ -844,6 +915,7 @@ static int rt_scene_destroy_impl(rt_scene* sc) {
     (void)hipFree(sc->d_stack_ovf);
     if (sc->ovf_done) (void)hipEventDestroy(sc->ovf_done);
     (void)hipFree(sc->d_geom_r);
+    (void)hipFree(sc->d_big);
     (void)hipFree(sc->d_leaf_of);
     (void)hipFree(sc->d_counters);
     (void)hipFree(sc->d_out);

@@ -45,6 +45,12 @@ constexpr int BLOCK = 256;       // 4 waves
 #ifndef RT_MINWAVES_LTREE       // LDS-resident tree: one workgroup of 16 waves per CU = 4 per SIMD, 128 VGPRs
 #define RT_MINWAVES_LTREE 4
 #endif
+#ifndef RT_MINWAVES_CULL
+#define RT_MINWAVES_CULL 5
+#endif
+#ifndef RT_CULL_FLUSH_MIN       // culled walk: a lane without a hit root-tests its leaves at a check once it holds this many
+#define RT_CULL_FLUSH_MIN 1
+#endif
 #ifndef RT_MINWAVES_QTRAV       // quantised-node kernels: 96 VGPRs, no spill slots (unbounded they take 97-99 = 4 waves/SIMD)
 #define RT_MINWAVES_QTRAV 5
 #endif
@@ -134,6 +140,9 @@ struct KParams {
     uint32_t stack_lds;          // capped quantised-node kernel: stack entries per lane kept in LDS, deeper ones go to stack_ovf
     uint32_t ovf_stride;         //   threads in the grid (stride of the overflow area)
     uint32_t* stack_ovf;         //   [entries beyond stack_lds][ovf_stride]
+    const uint32_t* big;         // culled walk (ISECT 7): [n_big] spheres too large for the culling slack, root-tested at query start
+    uint32_t n_big;
+    float r_slack;               //   largest radius among the spheres NOT in big[]
     uint32_t refill_eighths;     // traversal: finished lanes are refilled once <= this many eighths of the live lanes still walk
     uint32_t n_internal;         // internal nodes of the tree (= TravNode count)
     uint32_t lds_node_off;       // LDS-resident tree (ISECT 5): byte offsets of the staged nodes ...
@@ -373,11 +382,14 @@ __device__ __forceinline__ void consider(Hit& h, int idx, V3 o, V3 d, float t, c
 }
 
 // index-order first minimum over the primitives that satisfy `admitted` (evaluated only for an improving hit)
-template <class Pred>
-__device__ __forceinline__ void consider_if(Hit& h, int idx, V3 o, V3 d, float t, Pred admitted) {
+// RANKED: the candidates arrive in any order (culled walk), so an equal distance goes to the earlier depth-first leaf explicitly.
+template <bool RANKED = false, class Pred>
+__device__ __forceinline__ void consider_if(Hit& h, int idx, V3 o, V3 d, float t, Pred admitted, const uint32_t* __restrict__ leaf_of = nullptr) {
     V3 p = o + t * d;
     float dist = vlength(p - o);
-    if (!(h.idx < 0 || h.dist > dist)) return;
+    if (!(h.idx < 0 || h.dist > dist)) {
+        if (!(RANKED && h.dist == dist && leaf_of[idx] < leaf_of[h.idx])) return;
+    }
     if (!admitted()) return;
     h.idx = idx;
     h.dist = dist;
@@ -440,17 +452,32 @@ __device__ __forceinline__ const T& at32(const T* __restrict__ base, uint32_t i)
     return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + i * (uint32_t)sizeof(T));
 }
 
+// Distance culling bound of the culled walk (ISECT 7).  A sphere X whose own AABB the ray enters at t_X
+// and whose reference root test returns x satisfies x >= t_X - sqrt(2) r_X - 2^-9 |o - c_X| - 2^-21.4 |o - c_X|^2 (genuine
+// roots lie in the box up to the rounding of the reference's quadratic; false roots of a near miss lie within 2^-9 |oc| of
+// the closest approach, which is at most sqrt(2) r behind the box entry), |o - c_X| <= 1.01 (x + 2 r_X), and the compared
+// distance |P - o| is x up to 2^-20 x + 2^-22 |o|_1.  Hence nothing entered beyond the value returned here can reach
+// `best` or tie with it.  (The walk's boxes contain the exact ones, so their entry is not later than t_X.)
+__device__ __forceinline__ float cull_bound(float best, V3 o, float r_slack) {
+    const float a = 1.5f * r_slack + 0x1p-18f * (__builtin_fabsf(o.x) + __builtin_fabsf(o.y) + __builtin_fabsf(o.z));
+    const float q = best + 2.0f * r_slack;
+    return (best + a) * (1.0f + 0x1p-8f) + 0x1p-19f * (q * q);
+}
+
 // ------------------------------------------------------------------ the kernel
 // ISECT selects the closest-hit engine: 0 = linear scan, scene resident in LDS; 1 = linear scan, scene streamed
 // through LDS in chunks; 2 = per-lane traversal of the reference BVH (exact 64-byte nodes); 3 = the same walk over
 // 32-byte nodes whose boxes are rounded outwards onto a 16-bit grid, every reached leaf being validated with the
 // reference's exact own-leaf AABB test.
 template <int ISECT, bool EXPANDED, int BS = BLOCK, bool STATS = false>
-__global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 3 ? RT_MINWAVES_QTRAV : ISECT == 2 ? RT_MINWAVES_TRAV : RT_MINWAVES) void rt_tile_kernel(const KParams p) {
+__global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 7 ? RT_MINWAVES_CULL : ISECT >= 3 ? RT_MINWAVES_QTRAV : ISECT == 2 ? RT_MINWAVES_TRAV : RT_MINWAVES) void rt_tile_kernel(const KParams p) {
     constexpr int BLOCK = BS;                        // threads per workgroup = stride of the per-lane LDS arrays
     constexpr bool STREAMED = (ISECT == 1);
     constexpr bool TRAVERSE = (ISECT >= 2);
-    constexpr bool QNODES = (ISECT == 3 || ISECT == 4);   // traversal over 32-byte conservatively quantised nodes
+    constexpr bool QNODES = (ISECT == 3 || ISECT == 4 || ISECT == 7);   // traversal over 32-byte conservatively quantised nodes
+    // ISECT 7: ... nearer child first, and a subtree whose box the ray enters beyond the running closest hit (plus a proven
+    // slack, cull_bound) is not entered.  Spheres only.  Candidates then arrive out of depth-first order: ties by rank.
+    constexpr bool CULL = (ISECT == 7);
     constexpr bool CAPPED = (ISECT == 4);            // ... whose stack keeps p.stack_lds entries in LDS, deeper ones in HBM
     // ISECT 5: the exact-node walk with the WHOLE tree (and the materials) resident in LDS, one 1024-thread workgroup
     // per CU; references, stack and leaf lists are 16-bit
@@ -562,6 +589,7 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 3 ? R
     uint32_t t_ref = 0, t_sp = 0, t_cnt = 0;
     V3 ig = mk(0, 0, 0), cq = mk(0, 0, 0);   // QNODES: the ray in grid units, t(q) = q * ig + cq
     bool qfin = false;                       // QNODES: this lane may use the quantised boxes
+    float t_far = __builtin_inff();          // CULL: no primitive entered beyond this distance can beat the running hit
     uint32_t* lc32 = reinterpret_cast<uint32_t*>(lds_raw + p.lds_cand_off);     // TRAVERSE: leaf candidates (u32)
     uint32_t* lstack = reinterpret_cast<uint32_t*>(lds_raw + p.lds_stack_off);   // TRAVERSE: per-lane stack
     uint32_t sgx = 0, sgy = 0, sgz = 0;      // LTREE: (direction.axis < 0) of the current query, ray.rs:139-141
@@ -587,7 +615,7 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 3 ? R
     // Compiled into the kernels whose gathers churn L2 (the L2-gather walks, the streamed scan): there a pixel's line
     // is evicted half written.  The LDS-tree and resident-scan kernels leave L2 to the frame: their byte stores merge
     // there into whole lines (c3: WRITE_SIZE 1.03 x the frame either way, profiles/r02_*), staging only cost registers.
-    constexpr bool CAN_STAGE = (ISECT >= 1 && ISECT <= 4);
+    constexpr bool CAN_STAGE = (ISECT >= 1 && ISECT <= 4) || ISECT == 7;
     const bool staging = CAN_STAGE && p.lds_stage_off != 0xffffffffu;
     unsigned char* const stage_base = lds_raw + (staging ? p.lds_stage_off + (uint32_t)(tid >> 6) * STAGE_BYTES : 0u);
     int s_left0 = -1, s_left1 = -1, s_left2 = -1;
@@ -805,6 +833,19 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 3 ? R
                 sgy = aux.sy ? 1u : 0u;
                 sgz = aux.sz ? 1u : 0u;
             }
+            if (CULL) {
+                // spheres too large for the culling slack (a ground sphere) are root-tested here, under the same candidate
+                // rule as any leaf; meeting them again in the walk changes nothing
+                t_far = __builtin_inff();
+                for (uint32_t j = 0; j < p.n_big; j++) {
+                    const uint32_t prim = p.big[j];
+                    const float4 g = at32(p.geom, prim);
+                    float t;
+                    if (exact_sphere(o, 2.0f * d, mk(g.x, g.y, g.z), g.w, p.t_min, p.t_max, t))
+                        consider_if<true>(h, (int)prim, o, d, t, [&]() { return bvh_reaches(p.bvh_nodes, p.leaf_of[prim], o, aux); }, p.leaf_of);
+                }
+                if (h.idx >= 0) t_far = cull_bound(h.dist, o, p.r_slack);
+            }
             if (TRAVERSE) {
                 t_ref = p.root_ref;
                 t_sp = BFSTEP ? 1u : 0u;                     // slot 0 of the branch-free step's stack holds the DONE sentinel
@@ -836,12 +877,12 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 3 ? R
                         const float4 g = at32(p.geom, prim);
                         if (exact_sphere(o, 2.0f * d, mk(g.x, g.y, g.z), g.w, p.t_min, p.t_max, t)) {   // (2f32 * ray.direction), sphere.rs:44
                             if (QNODES)
-                                consider_if(h, (int)prim, o, d, t, [&]() {
+                                consider_if<CULL>(h, (int)prim, o, d, t, [&]() {
                                     if (!qfin || (p.n_sph + p.n_tri) == 1) return true;
                                     const float4 s = at32(p.geom_r, prim);
                                     return intersects_aabb_finite(o, aux, make_float4(s.x - s.w, s.y - s.w, s.z - s.w, 0.f),
                                                                   make_float4(s.x + s.w, s.y + s.w, s.z + s.w, 0.f));
-                                });
+                                }, p.leaf_of);
                             else
                                 consider<0>(h, (int)prim, o, d, t, aux, p.bvh_nodes, p.leaf_of);
                         }
@@ -856,6 +897,7 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 3 ? R
                     }
                 }
                 t_cnt = 0;
+                if (CULL && h.idx >= 0) t_far = cull_bound(h.dist, o, p.r_slack);
             };
             // Per-lane stack.  The exact-node kernel keeps all of it in LDS ((depth + 1) KiB per workgroup); the quantised
             // kernel (large scenes, deep trees) keeps p.stack_lds entries there and the rare deeper ones in HBM, so
@@ -972,7 +1014,8 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 3 ? R
 #ifndef RT_FLUSH_INLINE
                 // a lane whose leaf list is full waits at its leaf until this point (keeps the root tests out of the
                 // unrolled step code: one copy instead of RT_STEPS_PER_CHECK; c3 +1 %, 45 % less code)
-                if (in_trav && t_cnt == ML) flush();
+                // (CULL: a lane without a hit yet tests its leaves now, so that the walk can start skipping)
+                if (in_trav && (t_cnt == ML || (CULL && t_cnt >= (uint32_t)RT_CULL_FLUSH_MIN && h.idx < 0))) flush();
 #endif
 #ifdef RT_ROLL_STEPS
 #pragma clang loop unroll(disable)
@@ -1044,8 +1087,20 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 3 ? R
                                                                     __builtin_fminf(rz0, rz1));
                                 const float rmax_ = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(rx0, rx1), __builtin_fmaxf(ry0, ry1)),
                                                                     __builtin_fmaxf(rz0, rz1));
-                                hl = __builtin_fmaxf(lmin, 0.0f) <= lmax;
-                                hr = __builtin_fmaxf(rmin_, 0.0f) <= rmax_;
+                                if (CULL) {
+                                    // the exit clipped to t_far: a box entered beyond it is skipped; the nearer child first
+                                    const float le = __builtin_fmaxf(lmin, 0.0f), re = __builtin_fmaxf(rmin_, 0.0f);
+                                    hl = le <= __builtin_fminf(lmax, t_far);
+                                    hr = re <= __builtin_fminf(rmax_, t_far);
+                                    if (hl && hr && re < le) {
+                                        const uint32_t t = cl;
+                                        cl = cr;
+                                        cr = t;
+                                    }
+                                } else {
+                                    hl = __builtin_fmaxf(lmin, 0.0f) <= lmax;
+                                    hr = __builtin_fmaxf(rmin_, 0.0f) <= rmax_;
+                                }
                             } else {
                                 // +-0 direction component (inverse = +-inf): the monotonicity argument does not hold, so
                                 // this lane walks the exact nodes with the crate's literal test; its leaves need no validation
@@ -1367,6 +1422,7 @@ using KernelFn = void (*)(const KParams);
 KernelFn kernel_linear(bool streamed, bool expanded);
 KernelFn kernel_traverse(int variant, bool stats = false);   // 0: exact nodes, 1: quantised nodes, 2: quantised nodes with the capped LDS stack,
                                          // 3: exact nodes, whole tree resident in LDS (1024-thread workgroups)
+                                         // 5: quantised nodes, nearer child first, distance culling (spheres only)
                                          // stats: the variant that also counts node visits (RT_FLAG_COUNT_STEPS)
 constexpr int LTREE_BLOCK = 1024;
 

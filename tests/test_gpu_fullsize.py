@@ -124,15 +124,19 @@ def test_c5_65536_spheres_streamed_full_frame(ndev, oracle):
     assert st.exact_fallbacks <= st.ray_segments // 1000
     # default engine for 65 536 spheres is the BVH traversal; the LDS-streamed linear scan agrees on a strip,
     # with the leaf-box shortcut of its BVH validation and with the whole chain walked (RT_FLAG_FULL_CHAIN)
-    # (at this size over the 32-byte quantised nodes; the exact 64-byte nodes give the same strip)
-    assert st.engine == 3
+    # (at this size over the 32-byte quantised nodes, nearer child first with distance culling — the host heuristic finds
+    # c5 dense enough; the plain quantised walk (flag 2048) and the exact 64-byte nodes (flag 64) give the same strip)
+    assert st.engine == 5
     r0 = rq.copy()
     r0.division_no, r0.flags = 11, 32
     with rt.Scene(0, rt.World(sph)) as sc:
         lin_strip, _, st_lin = sc.render_tile(r0)
         r0.flags = 64
         ex_strip, _, st_ex = sc.render_tile(r0)
+        r0.flags = 2048
+        q_strip, _, st_q = sc.render_tile(r0)
     assert st_ex.engine == 2 and np.array_equal(ex_strip, lin_strip)
+    assert st_q.engine == 3 and np.array_equal(q_strip, lin_strip) and st_q.ray_segments == st_lin.ray_segments
     strip0 = rgb.size // rq.divisions
     assert np.array_equal(lin_strip, rgb[11 * strip0:12 * strip0])
     r1 = rq.copy()

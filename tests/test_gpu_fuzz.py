@@ -16,7 +16,11 @@ ENGINE_FLAGS = [0, _abi.RT_FLAG_LINEAR_SCAN, _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT
                 _abi.RT_FLAG_NO_BVH_CULL, _abi.RT_FLAG_EXACT_SCAN, _abi.RT_FLAG_LINEAR_SCAN | _abi.RT_FLAG_FULL_CHAIN,
                 # small trees walk an LDS-resident copy by default; keep the L2-gather walks of the same nodes covered
                 _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_EXACT_NODES | _abi.RT_FLAG_NO_LDS_TREE,
-                _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_FULL_CHAIN | _abi.RT_FLAG_NO_LDS_TREE]
+                _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_FULL_CHAIN | _abi.RT_FLAG_NO_LDS_TREE,
+                # the culled walk (nearer child first, distance culling) forced onto small scenes (sphere-only ones take it)
+                _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_QUANT_NODES | _abi.RT_FLAG_CULL_WALK,
+                _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_QUANT_NODES | _abi.RT_FLAG_CULL_WALK | _abi.RT_FLAG_FULL_CHAIN,
+                _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_QUANT_NODES | _abi.RT_FLAG_NO_CULL_WALK]
 
 
 @pytest.fixture(scope="module")
@@ -106,7 +110,8 @@ def _big_case(i):
     sph["emission"] = np.where(g.uniform(size=n) < 0.03, g.uniform(2, 6, n), 0.0)
     rq = _abi.default_request(width=int(g.choice([160, 256])), height=int(g.choice([90, 144])), divisions=1, spp=2,
                               max_bounces=int(g.choice([4, 8])), seed=int(g.integers(0, 2**63)))
-    flags = [0, _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_QUANT_NODES, _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_EXACT_NODES][i % 3]
+    flags = [0, _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_QUANT_NODES | _abi.RT_FLAG_CULL_WALK, _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_EXACT_NODES,
+             _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_QUANT_NODES | _abi.RT_FLAG_NO_CULL_WALK][(i // 4 + i) % 4]
     return sph, rq, flags
 
 
@@ -121,7 +126,17 @@ def test_fuzz_big_scene(ndev, oracle, i):
     r.flags = flags
     with rt.Scene(0, rt.World(sph)) as sc:
         rgb, f32, st = sc.render_tile(r, want_f32=True)
-    assert st.engine in (2, 3)
+    assert st.engine in (2, 3, 5)
+    _BIG_ENGINES.append(st.engine)
     assert np.array_equal(rgb, ref), f"big case {i}: {int((rgb != ref).sum())} bytes differ (flags {flags}, engine {st.engine})"
     assert np.array_equal(f32.view(np.uint32), ref_f.view(np.uint32)), f"big case {i}"
     assert st.ray_segments == info["ray_segments"], f"big case {i}"
+
+
+_BIG_ENGINES = []
+
+
+def test_big_cases_covered_plain_and_culled_walks(ndev):
+    if len(_BIG_ENGINES) < 6:
+        pytest.skip("big cases did not run")
+    assert 3 in _BIG_ENGINES and 5 in _BIG_ENGINES, _BIG_ENGINES

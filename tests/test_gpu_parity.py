@@ -191,7 +191,9 @@ def test_bvh_traversal_engine(ndev, oracle, scene):
     else:
         sph = scenes.rand65536(n=9000)
         rq = _abi.default_request(width=128, height=80, divisions=1, spp=2, max_bounces=5, seed=99)
-    a = _compare(oracle, rq, sph, tri, flags=_abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_QUANT_NODES)
+    a = _compare(oracle, rq, sph, tri, flags=_abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_QUANT_NODES | _abi.RT_FLAG_NO_CULL_WALK)
+    # the same nodes nearer child first with distance culling (sphere scenes; a mesh keeps the plain walk)
+    k = _compare(oracle, rq, sph, tri, flags=_abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_QUANT_NODES | _abi.RT_FLAG_CULL_WALK)
     c = _compare(oracle, rq, sph, tri, flags=_abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_EXACT_NODES | _abi.RT_FLAG_NO_LDS_TREE)
     b = _compare(oracle, rq, sph, tri, flags=_abi.RT_FLAG_LINEAR_SCAN)
     # the exact nodes walked from an LDS-resident copy (the default for trees that fit; a single-leaf tree has no nodes)
@@ -201,6 +203,9 @@ def test_bvh_traversal_engine(ndev, oracle, scene):
     assert e.engine == (4 if scene in ("c2", "c3", "mesh") else 2)
     assert e.broad_candidates == c.broad_candidates                    # same tree, same leaves reached
     assert a.broad_candidates >= c.broad_candidates                    # rounded boxes can only admit more leaves
+    assert k.ray_segments == a.ray_segments and k.broad_candidates <= a.broad_candidates    # culling only skips
+    if scene != "single":
+        assert a.engine == 3 and k.engine == (3 if scene == "mesh" else 5)
 
 
 def test_strips_equal_whole_frame(ndev):
@@ -606,7 +611,8 @@ def test_controller_shim_two_overlapping_jobs(ndev, oracle):
         ctl.stop()
 
 
-@pytest.mark.parametrize("flags", [_abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_QUANT_NODES,
+@pytest.mark.parametrize("flags", [_abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_QUANT_NODES | _abi.RT_FLAG_NO_CULL_WALK,
+                                   _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_QUANT_NODES | _abi.RT_FLAG_CULL_WALK,
                                    _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_EXACT_NODES])
 def test_quantised_walk_fallback_lanes(ndev, oracle, flags):
     """Rays the grid form cannot carry walk the exact nodes inside the quantised kernel: (a) a tiny cluster seen from
@@ -626,6 +632,7 @@ def test_quantised_walk_fallback_lanes(ndev, oracle, flags):
     rq.fov = 0.02                                           # the cluster fills the frame
     st = _compare(oracle, rq, sph, flags=flags)
     assert st.ray_segments > rq.width * rq.height * rq.spp     # some paths did bounce
+    assert st.engine == (5 if flags & _abi.RT_FLAG_CULL_WALK else 3 if flags & _abi.RT_FLAG_QUANT_NODES else 4)
     # (b) mirror spheres on the optical axis, pinhole camera: reflected rays with exact zero components
     row = np.zeros(3, _abi.SPHERE_DTYPE)
     row["cz"] = [-4.0, -9.0, -2000.0]
@@ -634,6 +641,7 @@ def test_quantised_walk_fallback_lanes(ndev, oracle, flags):
     row["roughness"] = 1.0
     rq2 = _abi.default_request(width=65, height=65, divisions=1, spp=4, max_bounces=6, seed=9)
     rq2.aperture = 0.0
+    # (the three large spheres make the 16-bit grid too coarse for the cluster: the host falls back to the exact nodes here)
     _compare(oracle, rq2, np.concatenate([row, sph]), flags=flags)
 
 
