@@ -376,11 +376,11 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     // persistent grid: as many workgroups as the chip holds at this LDS/VGPR budget
     int per_cu = 0;
     const bool count_steps = traverse && (rq->flags & RT_FLAG_COUNT_STEPS);
-    const bool cull_run = cull && !capped;            // (a tree too deep for the LDS stack keeps the capped-stack kernel)
+    const bool cull_run = cull;
     p.big = sc->d_big;
     p.n_big = sc->n_big;
     p.r_slack = sc->r_slack;
-    const rtk::KernelFn kern = traverse ? rtk::kernel_traverse(ltree ? 3 : qnodes ? (capped ? 2 : cull_run ? 5 : 1) : 0, count_steps) : rtk::kernel_linear(streamed, expanded);
+    const rtk::KernelFn kern = traverse ? rtk::kernel_traverse(ltree ? 3 : qnodes ? (cull_run ? (capped ? 6 : 5) : capped ? 2 : 1) : 0, count_steps) : rtk::kernel_linear(streamed, expanded);
     HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, bs, lds));
     if (per_cu < 1) per_cu = 1;
     static const bool verbose = getenv("RT_VERBOSE") != nullptr;
@@ -546,7 +546,7 @@ static int ensure_ctx(DeviceCtx* c) {
         for (int expanded = 0; expanded < 2; expanded++)
             HIPCHK(hipFuncSetAttribute((const void*)rtk::kernel_linear(streamed != 0, expanded != 0),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
-    for (int variant = 0; variant < 6; variant++)
+    for (int variant = 0; variant < 7; variant++)
         for (int stats = 0; stats < 2; stats++)
             HIPCHK(hipFuncSetAttribute((const void*)rtk::kernel_traverse(variant, stats != 0),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));

@@ -470,15 +470,15 @@ __device__ __forceinline__ float cull_bound(float best, V3 o, float r_slack) {
 // 32-byte nodes whose boxes are rounded outwards onto a 16-bit grid, every reached leaf being validated with the
 // reference's exact own-leaf AABB test.
 template <int ISECT, bool EXPANDED, int BS = BLOCK, bool STATS = false>
-__global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 7 ? RT_MINWAVES_CULL : ISECT >= 3 ? RT_MINWAVES_QTRAV : ISECT == 2 ? RT_MINWAVES_TRAV : RT_MINWAVES) void rt_tile_kernel(const KParams p) {
+__global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 7 ? RT_MINWAVES_CULL : ISECT >= 3 ? RT_MINWAVES_QTRAV : ISECT == 2 ? RT_MINWAVES_TRAV : RT_MINWAVES) void rt_tile_kernel(const KParams p) {
     constexpr int BLOCK = BS;                        // threads per workgroup = stride of the per-lane LDS arrays
     constexpr bool STREAMED = (ISECT == 1);
     constexpr bool TRAVERSE = (ISECT >= 2);
-    constexpr bool QNODES = (ISECT == 3 || ISECT == 4 || ISECT == 7);   // traversal over 32-byte conservatively quantised nodes
+    constexpr bool QNODES = (ISECT == 3 || ISECT == 4 || ISECT == 7 || ISECT == 8);   // traversal over 32-byte conservatively quantised nodes
     // ISECT 7: ... nearer child first, and a subtree whose box the ray enters beyond the running closest hit (plus a proven
     // slack, cull_bound) is not entered.  Spheres only.  Candidates then arrive out of depth-first order: ties by rank.
-    constexpr bool CULL = (ISECT == 7);
-    constexpr bool CAPPED = (ISECT == 4);            // ... whose stack keeps p.stack_lds entries in LDS, deeper ones in HBM
+    constexpr bool CULL = (ISECT == 7 || ISECT == 8);      // (8: with the capped LDS stack)
+    constexpr bool CAPPED = (ISECT == 4 || ISECT == 8);            // ... whose stack keeps p.stack_lds entries in LDS, deeper ones in HBM
     // ISECT 5: the exact-node walk with the WHOLE tree (and the materials) resident in LDS, one 1024-thread workgroup
     // per CU; references, stack and leaf lists are 16-bit
     constexpr bool LTREE = (ISECT == 5);
@@ -615,7 +615,7 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 7 ? R
     // Compiled into the kernels whose gathers churn L2 (the L2-gather walks, the streamed scan): there a pixel's line
     // is evicted half written.  The LDS-tree and resident-scan kernels leave L2 to the frame: their byte stores merge
     // there into whole lines (c3: WRITE_SIZE 1.03 x the frame either way, profiles/r02_*), staging only cost registers.
-    constexpr bool CAN_STAGE = (ISECT >= 1 && ISECT <= 4) || ISECT == 7;
+    constexpr bool CAN_STAGE = (ISECT >= 1 && ISECT <= 4) || ISECT >= 7;
     const bool staging = CAN_STAGE && p.lds_stage_off != 0xffffffffu;
     unsigned char* const stage_base = lds_raw + (staging ? p.lds_stage_off + (uint32_t)(tid >> 6) * STAGE_BYTES : 0u);
     int s_left0 = -1, s_left1 = -1, s_left2 = -1;
@@ -1422,7 +1422,7 @@ using KernelFn = void (*)(const KParams);
 KernelFn kernel_linear(bool streamed, bool expanded);
 KernelFn kernel_traverse(int variant, bool stats = false);   // 0: exact nodes, 1: quantised nodes, 2: quantised nodes with the capped LDS stack,
                                          // 3: exact nodes, whole tree resident in LDS (1024-thread workgroups)
-                                         // 5: quantised nodes, nearer child first, distance culling (spheres only)
+                                         // 5: quantised nodes, nearer child first, distance culling (spheres only); 6: the same, capped LDS stack
                                          // stats: the variant that also counts node visits (RT_FLAG_COUNT_STEPS)
 constexpr int LTREE_BLOCK = 1024;
 

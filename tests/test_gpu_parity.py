@@ -449,15 +449,17 @@ def test_frame_dispatcher_strip_queue_and_pinning(ndev, oracle, monkeypatch):
             monkeypatch.delenv(k)
 
 
-def test_capped_stack_launches_on_two_streams(ndev, oracle, monkeypatch):
+@pytest.mark.parametrize("cull", [0, _abi.RT_FLAG_CULL_WALK])
+def test_capped_stack_launches_on_two_streams(ndev, oracle, monkeypatch, cull):
     """The capped-stack walk (stack entries beyond a few LDS slots live in one per-scene HBM area) enqueued on two
-    streams at once: the library chains such launches, so frames rendered 'concurrently' are still exact."""
+    streams at once: the library chains such launches, so frames rendered 'concurrently' are still exact.  Both the plain
+    and the culled walk have a capped-stack variant."""
     hip = C.CDLL("libamdhip64.so")
     monkeypatch.setenv("RT_FORCE_CAPPED", "1")
     monkeypatch.setenv("RT_STACK_LDS", "3")
     sph = scenes.rand65536(n=9000)
     rq = _abi.default_request(width=128, height=80, divisions=1, spp=2, max_bounces=5, seed=99,
-                              flags=_abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_QUANT_NODES)
+                              flags=_abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_QUANT_NODES | cull)
     nb = 128 * 80 * 3
     with rt.Scene(0, rt.World(sph)) as sc:                   # (the scene makes device 0 current for this thread)
         streams, outs = [], []
@@ -485,7 +487,7 @@ def test_capped_stack_launches_on_two_streams(ndev, oracle, monkeypatch):
             hip.hipFree(o)
         for s_ in streams:
             hip.hipStreamDestroy(s_)
-    assert st.engine == 3 and st.n_launches == 6
+    assert st.engine == (5 if cull else 3) and st.n_launches == 6
     for r, h in zip(reqs, got):
         want, _, _ = oracle.render(r, sph, backend=1)
         assert np.array_equal(h, want)
