@@ -113,6 +113,7 @@ struct rt_scene {
     uint32_t n_big = 0;
     float r_slack = 0.f;           //   largest radius among the other spheres
     bool cull_pays = false;        //   host heuristic: the scene is dense enough for the culled walk (build_host_scene)
+    float cull_density = 0.f;      //   the box density behind it
     rtbvh::QGrid grid;
     float leaf_density = 0.f;      // sum of primitive box areas / scene box area (node-format heuristic)
     bool quant_ok = false;         // quantised walk usable and worthwhile (grid step small against the primitives)
@@ -229,19 +230,25 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     // waves per SIMD win on the headline scene (c3 +1.5 %).  tools/crossover_q.py, DESIGN.md 4.7
     // (meshes keep the exact nodes: a quantised walk validates a triangle leaf by walking its box chain — two more gathers
     // per improving hit — and lost 2...16 % on the generated terrains of 7 200 and 100 352 triangles, tools/heuristics_matrix.py)
-    const bool qnodes = traverse && sc->quant_ok && !(rq->flags & RT_FLAG_EXACT_NODES) &&
-                        ((rq->flags & RT_FLAG_QUANT_NODES) || (n_prims >= RT_QNODES_MIN_PRIMS && sc->n_tri <= sc->n_sph));
     // LDS-resident tree (engine 4, kernel variant 3): the exact 64-byte nodes of a small scene staged into LDS by one
     // 1024-thread workgroup per CU, 16-bit references / stack / leaf lists.  RT_FLAG_NO_LDS_TREE forces the
     // L2-gather kernel (A/B runs, tests).
     static const bool ltree_env = [] { const char* e = getenv("RT_LDS_TREE"); return !e || atoi(e) != 0; }();
-    bool ltree = false;
+    bool ltree_fits = false;
     const size_t lt_lane = ((size_t)rtk::MAXL_LTREE + (size_t)(rq->max_bounces + 1) + (size_t)(sc->bvh_depth + 2)) * sizeof(uint16_t);
-    if (traverse && !qnodes && ltree_env && !(rq->flags & RT_FLAG_NO_LDS_TREE) && sc->n_internal > 0 && n_prims <= 0x7fffu &&
+    if (traverse && ltree_env && !(rq->flags & RT_FLAG_NO_LDS_TREE) && sc->n_internal > 0 && n_prims <= 0x7fffu &&
         ((size_t)sc->n_internal + 1) * rtk::LNODE_DW < 0x8000u) {
         const size_t fixed = ((size_t)sc->n_internal + 1) * (rtk::LNODE_DW * 4) + lt_lane * rtk::LTREE_BLOCK;   // + the DONE node
-        ltree = fixed <= LDS_LIMIT;
+        ltree_fits = fixed <= LDS_LIMIT;
     }
+    // (Below the threshold a DENSE sphere scene whose tree does not fit LDS also takes the quantised nodes, for the culled
+    // walk below: tools/cull_matrix_small.py, 2 000...3 500 overlapping spheres 1.55...1.95 x over the exact-node walk, fields of
+    // box density 1...2 0.87...0.98 — hence the higher bar of 2.5 here.)
+    const bool dense_mid = !ltree_fits && sc->cull_pays && sc->cull_density >= 2.5f && n_prims >= 512 &&
+                           !(rq->flags & RT_FLAG_NO_CULL_WALK);
+    const bool qnodes = traverse && sc->quant_ok && !(rq->flags & RT_FLAG_EXACT_NODES) &&
+                        ((rq->flags & RT_FLAG_QUANT_NODES) || (n_prims >= RT_QNODES_MIN_PRIMS && sc->n_tri <= sc->n_sph) || dense_mid);
+    const bool ltree = ltree_fits && !qnodes;
     // Culled walk (engine 5, kernel variant 5): the quantised walk nearer child first, subtrees beyond the running closest hit
     // skipped.  Spheres only (the bound is derived from the sphere root test's error terms).
     // Default where the host heuristic says it pays (cull_pays: DESIGN.md 4.7); RT_FLAG_CULL_WALK / RT_FLAG_NO_CULL_WALK
@@ -859,6 +866,7 @@ static int upload_scene(int device, const HostScene& hs, rt_scene** out) {
     sc->n_big = hs.n_big;
     sc->r_slack = hs.r_slack;
     sc->cull_pays = hs.cull_pays;
+    sc->cull_density = hs.cull_density;
     SC_CHK(hipMalloc(&sc->d_counters, COUNTER_WORDS * sizeof(unsigned long long)));
     SC_CHK(hipMemsetAsync(sc->d_counters, 0, COUNTER_WORDS * sizeof(unsigned long long), ctx->stream));
     SC_CHK(hipEventRecord(e1, ctx->stream));

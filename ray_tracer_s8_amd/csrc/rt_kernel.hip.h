@@ -1050,6 +1050,8 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 7 ? R
                             const uint4* __restrict__ nq = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.travq) + (t_ref << 5));
                             uint4 qa = nq[0], qb = nq[1];
                             asm volatile("" : "+v"(qb.x), "+v"(qb.y), "+v"(qb.z), "+v"(qb.w));   // keep the two 16-byte loads whole
+                            // (fetching the second half only after the first has arrived — an L1 hit instead of a second miss on a
+                            // line in flight — costs 7 % on c5: the step's latency matters more than the texture path's time)
                             cl = qb.z;
                             cr = qb.w;
 #ifdef RT_PROBE_EXTRA_GATHER
