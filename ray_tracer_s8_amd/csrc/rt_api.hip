@@ -267,7 +267,7 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     // ---- LDS plan of a traversal launch.  Occupancy is worth more than long leaf lists (c3: 6 workgroups per CU with
     // 7 slots +1.5 % over 5 with 8; c5: 5 with 5 slots +7.5 % over 4 with 8), and an uncapped stack more than either
     // (the HBM-overflow test on every push / pop costs 6...10 %).  So: the target number of workgroups per CU follows
-    // from the kernel's registers (exact nodes 6, quantised 5).  The exact-node kernel has 7 slots, fixed; the quantised
+    // from the kernel's registers (five waves per SIMD for both node formats).  The exact-node kernel has 7 slots, fixed; the quantised
     // kernel's lists shrink from MAXL down to MINL slots to reach its target, and a quantised walk whose whole stack still
     // does not fit takes the capped-stack kernel.
     // stack slots per lane: up to bvh_depth pending right children (+ 1 spare); the LDS-tree kernel's branch-free step

@@ -40,7 +40,8 @@ constexpr int BLOCK = 256;       // 4 waves
 #define RT_MINWAVES 4
 #endif
 #ifndef RT_MINWAVES_TRAV
-#define RT_MINWAVES_TRAV 6       // exact-node kernel: 80 VGPRs, 2 spill slots outside the loops; c3 +1 %, c4 +2 % over 5
+#define RT_MINWAVES_TRAV 5       // exact-node L2 kernel: 96 VGPRs, no spills.  (6 waves / 80 VGPRs / 10 spilled registers was +1 % on c3 when
+                                 // c3 still ran here; on what it serves now — meshes, mid-size fields — 5 is +3...8 % / +0...1 %, tools/ab_trav.sh)
 #endif
 #ifndef RT_MINWAVES_LTREE       // LDS-resident tree: one workgroup of 16 waves per CU = 4 per SIMD, 128 VGPRs
 #define RT_MINWAVES_LTREE 4
