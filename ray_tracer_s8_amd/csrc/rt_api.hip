@@ -321,6 +321,14 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
         off += (size_t)stack_need * bs * sizeof(uint16_t);
         lds = off;
     }
+    // compacted root tests of the exact-node L2 kernel (1 KiB per wave; RT_COMPACT=0 keeps the per-lane flush for A/B runs)
+    p.lds_cmp_off = 0xffffffffu;
+    static const bool compact_env = [] { const char* e = getenv("RT_COMPACT"); return !e || atoi(e) != 0; }();
+    if (traverse && !qnodes && !ltree && compact_env && lds + 1024u * (rtk::BLOCK / 64) + 16 <= LDS_LIMIT) {
+        lds = (lds + 15) & ~(size_t)15;
+        p.lds_cmp_off = (uint32_t)lds;
+        lds += 1024u * (rtk::BLOCK / 64);
+    }
     p.lds_stage_off = 0xffffffffu;
     if (want_stage && lds + stage_bytes_wg <= LDS_LIMIT) {
         lds = (lds + 15) & ~(size_t)15;

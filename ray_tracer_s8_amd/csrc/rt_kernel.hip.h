@@ -114,6 +114,7 @@ struct KParams {
     uint32_t lds_path_off;
     uint32_t lds_rr_off;
     uint32_t lds_stack_off;      // traversal engine: per-lane stack, (bvh depth + 1) x 256 x u32
+    uint32_t lds_cmp_off;        // compacted root tests (ISECT 2): 1 KiB per wave (offsets, distances, roots, hit flags); 0xffffffff: per-lane flush
     uint32_t lds_stage_off;      // output staging (STAGE_BYTES per wave); 0xffffffff: every pixel is stored directly
     uint32_t n_strips;           // strips in this launch
     uint32_t tiles_x, tiles_per_strip, n_tiles;   // tiles of 64 pixels: (1 << tile_wlog2) wide
@@ -900,6 +901,97 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 7 ? R
                 t_cnt = 0;
                 if (CULL && h.idx >= 0) t_far = cull_bound(h.dist, o, p.r_slack);
             };
+            // ---- Compacted root tests (exact-node L2 kernel).  The per-lane flush above runs as many rounds as the longest
+            // list of the wave, each at a handful of lanes (mesh workload: 17 rounds of 5.7 lanes per loop round, half of the
+            // kernel's instructions).  Here the (lane, candidate) PAIRS of all flushing lanes are numbered consecutively and
+            // pair j is tested by lane j mod 64 — full rounds of 64 — with the owner's ray fetched across lanes; the owner then
+            // takes the first minimum of its own pairs in list order, exactly as `consider<0>` does.  Wave-uniform call: every
+            // lane still in the loop takes part as a worker, `want` marks the lanes whose lists are flushed.
+            constexpr bool COMPACT = (ISECT == 2);
+            auto flush_c = [&](bool want) {
+                const uint32_t cnt = want ? t_cnt : 0u;
+                // exclusive prefix sum and total of the (at most 4-bit) counts from ballots: no cross-lane traffic
+                uint32_t excl = 0, total = 0;
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const unsigned long long m = __ballot(((cnt >> b) & 1u) != 0);
+                    excl += (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) << b;
+                    total += (uint32_t)__builtin_popcountll(m) << b;
+                }
+                // lanes that left the loop take no part: workers and table entries are numbered by RANK among the live lanes
+                const unsigned long long act = __ballot(true);
+                const uint32_t n_act = (uint32_t)__builtin_popcountll(act);
+                const uint32_t rank = (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
+                uint32_t* const w_pref = reinterpret_cast<uint32_t*>(lds_raw + p.lds_cmp_off) + (tid >> 6) * 256;   // offset | lane << 16
+                float* const w_dist = reinterpret_cast<float*>(w_pref + 64);
+                float* const w_root = reinterpret_cast<float*>(w_pref + 128);
+                uint32_t* const w_hit = w_pref + 192;
+                w_pref[rank] = excl | ((uint32_t)lane << 16);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                int best_k = -1;                                     // owner: slot of the winner among this flush's pairs
+                float best_t = 0.f;
+                for (uint32_t base = 0; base < total; base += n_act) {
+                    const uint32_t j = base + rank;
+                    const bool valid = j < total;
+                    // owner of pair j = the last live lane whose offset is <= j (lanes without candidates share the next one's)
+                    uint32_t R = 0, ent = w_pref[0];
+                    if (valid) {
+#pragma unroll
+                        for (uint32_t stp = 32; stp > 0; stp >>= 1) {
+                            const uint32_t c = R + stp;
+                            if (c < n_act) {
+                                const uint32_t e = w_pref[c];
+                                if ((e & 0xffffu) <= j) { R = c; ent = e; }
+                            }
+                        }
+                    }
+                    const uint32_t L = ent >> 16, slot = j - (ent & 0xffffu);
+                    // the owner's ray (cross-lane reads are executed by every lane of the round)
+                    const V3 ro = mk(__shfl(o.x, (int)L, 64), __shfl(o.y, (int)L, 64), __shfl(o.z, (int)L, 64));
+                    const V3 rd = mk(__shfl(d.x, (int)L, 64), __shfl(d.y, (int)L, 64), __shfl(d.z, (int)L, 64));
+                    bool hit = false;
+                    float t = 0.f, dist = 0.f;
+                    if (valid) {
+                        const uint32_t ot = ((uint32_t)tid & ~63u) | L;                              // the owner's thread and 16-bit column
+                        const uint32_t ot16 = (ot & ~63u) | ((ot & 31u) << 1) | ((ot >> 5) & 1u);
+                        const uint32_t prim = p.list16 ? (uint32_t)lc16[slot * BLOCK + ot16] : lc32[slot * BLOCK + ot];
+                        if (prim < p.n_sph) {
+                            const float4 g = at32(p.geom, prim);
+                            hit = exact_sphere(ro, 2.0f * rd, mk(g.x, g.y, g.z), g.w, p.t_min, p.t_max, t);   // (2f32 * ray.direction), sphere.rs:44
+                        } else {
+                            hit = exact_triangle(ro, rd, p.tri + 9 * (size_t)(prim - p.n_sph), p.t_min, p.t_max, t);
+                        }
+                        if (hit) {
+                            const V3 pp = ro + t * rd;               // Ray::at, then |P - o| (consider)
+                            dist = vlength(pp - ro);
+                        }
+                    }
+                    w_dist[rank] = dist;
+                    w_root[rank] = t;
+                    w_hit[rank] = hit ? 1u : 0u;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    // owners: first minimum over their pairs of this round, in list order (consider<0>)
+                    if (cnt) {
+                        const uint32_t k0 = excl > base ? excl : base, k1 = min(excl + cnt, base + n_act);
+#pragma clang loop unroll(disable)
+                        for (uint32_t k = k0; k < k1; k++) {
+                            if (!w_hit[k - base]) continue;
+                            const float dk = w_dist[k - base];
+                            if (best_k < 0 ? (h.idx < 0 || h.dist > dk) : (h.dist > dk)) {
+                                h.dist = dk;
+                                best_k = (int)(k - excl);
+                                best_t = w_root[k - base];
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // reads done before the next round's writes
+                }
+                if (best_k >= 0) {
+                    h.idx = (int)(p.list16 ? (uint32_t)lc16[(uint32_t)best_k * BLOCK + tid16] : lc32[(uint32_t)best_k * BLOCK + tid]);
+                    h.p = o + best_t * d;
+                }
+                if (want) t_cnt = 0;
+            };
             // Per-lane stack.  The exact-node kernel keeps all of it in LDS ((depth + 1) KiB per workgroup); the quantised
             // kernel (large scenes, deep trees) keeps p.stack_lds entries there and the rare deeper ones in HBM, so
             // that the tree's depth does not take the CU's LDS away from its occupancy.
@@ -1016,6 +1108,10 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 7 ? R
                 // a lane whose leaf list is full waits at its leaf until this point (keeps the root tests out of the
                 // unrolled step code: one copy instead of RT_STEPS_PER_CHECK; c3 +1 %, 45 % less code)
                 // (CULL: a lane without a hit yet tests its leaves now, so that the walk can start skipping)
+                if (COMPACT && p.lds_cmp_off != 0xffffffffu) {
+                    const bool want = in_trav && t_cnt == ML;
+                    if (__ballot(want)) flush_c(want);
+                } else
                 if (in_trav && (t_cnt == ML || (CULL && t_cnt >= (uint32_t)RT_CULL_FLUSH_MIN && h.idx < 0))) flush();
 #endif
 #ifdef RT_ROLL_STEPS
@@ -1139,6 +1235,10 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 7 ? R
             }
             }
             TSTAMP(2);
+            if (COMPACT && p.lds_cmp_off != 0xffffffffu) {
+                const bool want = active && !in_trav && t_cnt > 0;
+                if (__ballot(want)) flush_c(want);
+            } else
             if (active && !in_trav) flush();                 // exact root tests of the finished lanes, together
             TSTAMP(3);
         } else {

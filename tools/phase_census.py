@@ -9,14 +9,14 @@ import numpy as np, torch
 import ray_tracer_s8_amd as rt
 from ray_tracer_s8_amd import scenes, _abi
 rt.init()
-sph, rq = scenes.config(sys.argv[1] if len(sys.argv) > 1 else "c3")
+sph, tri, rq = scenes.config_world(sys.argv[1] if len(sys.argv) > 1 else "c3")
 reqs = []
 for k in range(rq.divisions):
     r = rq.copy(); r.division_no = k; r.flags = int(sys.argv[2]) if len(sys.argv) > 2 else 0; reqs.append(r)
 names = ["main-loop iterations", "pixel acquisition body", "camera gen", "UnitDisc loop iters", "broad pass-branch entries",
          "narrow loop iters", "exact hits -> consider", "bvh validation", "shade hit branch", "scatter (UnitSphere)",
          "UnitSphere loop iters", "sky branch", "finish", "path product loop iters", "pixel finalize"]
-with rt.Scene(0, rt.World(sph)) as sc:
+with rt.Scene(0, rt.World(sph, tri)) as sc:
     outs, _, st = sc.render_tiles(reqs)
     lib = _abi.load()
     # read raw counters through a tiny HIP memcpy via torch (device pointer is internal) -> use hip runtime

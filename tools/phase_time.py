@@ -9,7 +9,7 @@ build.build(force=True)
 import ray_tracer_s8_amd as rt
 from ray_tracer_s8_amd import scenes, _abi
 rt.init()
-sph, rq = scenes.config(sys.argv[1] if len(sys.argv) > 1 else "c3")
+sph, tri, rq = scenes.config_world(sys.argv[1] if len(sys.argv) > 1 else "c3")
 reqs = []
 for k in range(rq.divisions):
     r = rq.copy(); r.division_no = k; r.flags = int(sys.argv[2]) if len(sys.argv) > 2 else 0; reqs.append(r)
@@ -17,7 +17,7 @@ names = ["pixel acquisition", "ray generation", "traversal steps (+ inline flush
          "shade + finish + store", "loop top / counter drain", "-", "-"]
 hip = C.CDLL("libamdhip64.so")
 nb = (rq.height // rq.divisions) * rq.width * 3
-with rt.Scene(0, rt.World(sph)) as sc:
+with rt.Scene(0, rt.World(sph, tri)) as sc:
     dbuf = C.c_void_p()
     assert hip.hipMalloc(C.byref(dbuf), C.c_size_t(nb * len(reqs))) == 0
     ptrs = [dbuf.value + i * nb for i in range(len(reqs))]
