@@ -952,6 +952,7 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 7 ? R
                     bool hit = false;
                     float t = 0.f, dist = 0.f;
                     if (valid) {
+                        LCOUNT(6);
                         const uint32_t ot = ((uint32_t)tid & ~63u) | L;                              // the owner's thread and 16-bit column
                         const uint32_t ot16 = (ot & ~63u) | ((ot & 31u) << 1) | ((ot >> 5) & 1u);
                         const uint32_t prim = p.list16 ? (uint32_t)lc16[slot * BLOCK + ot16] : lc32[slot * BLOCK + ot];
