@@ -40,14 +40,22 @@ constexpr int BLOCK = 256;       // 4 waves
 #define RT_MINWAVES 4
 #endif
 #ifndef RT_MINWAVES_TRAV
-#define RT_MINWAVES_TRAV 5       // exact-node L2 kernel: 96 VGPRs, no spills.  (6 waves / 80 VGPRs / 10 spilled registers was +1 % on c3 when
-                                 // c3 still ran here; on what it serves now — meshes, mid-size fields — 5 is +3...8 % / +0...1 %, tools/ab_trav.sh)
+#define RT_MINWAVES_TRAV 4       // exact-node L2 kernel: no spills.  History: 6 waves / 80 VGPRs / 10 spilled registers was +1 % on c3 when c3
+                                 // still ran here; on what it serves now (meshes — whose deep trees leave LDS for four workgroups per CU
+                                 // anyway — and mid-size fields) 5 was +3...8 % / +0...1 % over 6, and with the compacted root tests and the
+                                 // straight-line step 4 another +1...6 % / +0...3 % over 5 (tools/ab_trav.sh)
 #endif
 #ifndef RT_MINWAVES_LTREE       // LDS-resident tree: one workgroup of 16 waves per CU = 4 per SIMD, 128 VGPRs
 #define RT_MINWAVES_LTREE 4
 #endif
 #ifndef RT_MINWAVES_CULL
 #define RT_MINWAVES_CULL 5
+#endif
+#ifndef RT_STEPS_PER_CHECK_X    // exact-node L2 kernel, straight-line step
+#define RT_STEPS_PER_CHECK_X 16
+#endif
+#ifndef RT_BF2                  // straight-line step in the uncapped quantised walks (see there)
+#define RT_BF2 1
 #endif
 #ifndef RT_CULL_FLUSH_MIN       // culled walk: a lane without a hit root-tests its leaves at a check once it holds this many
 #define RT_CULL_FLUSH_MIN 1
@@ -1115,6 +1123,75 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 7 ? R
                 } else
                 if (in_trav && (t_cnt == ML || (CULL && t_cnt >= (uint32_t)RT_CULL_FLUSH_MIN && h.idx < 0))) flush();
 #endif
+                // ---- Straight-line step of the uncapped quantised walks (RT_BF2).  The step below this one spends more
+                // instructions on exec-mask bookkeeping (14 regions) than on the two slab tests; with the gathers no longer the
+                // only bound (culled walk) the wave's serial instruction stream matters here as it did for the LDS tree.  One
+                // region per step (the lane still walks), everything else through selects: a lane at a leaf fetches node 0 (a
+                // hot line) and fails both tests, so it appends and pops; a full list stalls the lane until the flush between
+                // blocks; the right child is stored to the free stack slot pushed or not.  Taken when every walking lane of the
+                // wave carries its ray in grid units; a wave with a fallback lane runs the step below.
+                constexpr bool BF2 = (RT_BF2 != 0) && (ISECT == 2 || ISECT == 3 || ISECT == 7);
+                if (BF2 && !__ballot(in_trav && !(QNODES ? qfin : aux.finite))) {
+#pragma unroll
+                    for (int rep = 0; rep < (QNODES ? RT_STEPS_PER_CHECK_Q : RT_STEPS_PER_CHECK_X); rep++)
+                    if (in_trav) {
+                        WCOUNT(5);
+                        LCOUNT(5);
+                        const bool is_leaf = (t_ref & LEAF_BIT) != 0;
+                        if (STATS) n_int += is_leaf ? 0u : 1u;
+                        const uint32_t top = lstack[(t_sp - (t_sp ? 1u : 0u)) * BLOCK + tid];   // what a pop would yield
+                        bool hl, hr;
+                        float le = 0.f, re = 0.f;
+                        uint32_t c0, c1;                                            // left, right child reference
+                        if constexpr (QNODES) {
+                        const uint4* __restrict__ nq = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.travq) + ((is_leaf ? 0u : t_ref) << 5));
+                        uint4 qa = nq[0], qb = nq[1];
+                        asm volatile("" : "+v"(qb.x), "+v"(qb.y), "+v"(qb.z), "+v"(qb.w));   // keep the two 16-byte loads whole
+#define RT_Q(word, hi16) ((float)((hi16) ? ((word) >> 16) : ((word) & 0xffffu)))
+                        const float lx0 = __builtin_fmaf(RT_Q(qa.x, 0), ig.x, cq.x), lx1 = __builtin_fmaf(RT_Q(qa.y, 1), ig.x, cq.x);
+                        const float ly0 = __builtin_fmaf(RT_Q(qa.x, 1), ig.y, cq.y), ly1 = __builtin_fmaf(RT_Q(qa.z, 0), ig.y, cq.y);
+                        const float lz0 = __builtin_fmaf(RT_Q(qa.y, 0), ig.z, cq.z), lz1 = __builtin_fmaf(RT_Q(qa.z, 1), ig.z, cq.z);
+                        const float rx0 = __builtin_fmaf(RT_Q(qa.w, 0), ig.x, cq.x), rx1 = __builtin_fmaf(RT_Q(qb.x, 1), ig.x, cq.x);
+                        const float ry0 = __builtin_fmaf(RT_Q(qa.w, 1), ig.y, cq.y), ry1 = __builtin_fmaf(RT_Q(qb.y, 0), ig.y, cq.y);
+                        const float rz0 = __builtin_fmaf(RT_Q(qb.x, 0), ig.z, cq.z), rz1 = __builtin_fmaf(RT_Q(qb.y, 1), ig.z, cq.z);
+#undef RT_Q
+                        const float lmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(lx0, lx1), __builtin_fminf(ly0, ly1)), __builtin_fminf(lz0, lz1));
+                        const float lmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(lx0, lx1), __builtin_fmaxf(ly0, ly1)), __builtin_fmaxf(lz0, lz1));
+                        const float rmin_ = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(rx0, rx1), __builtin_fminf(ry0, ry1)), __builtin_fminf(rz0, rz1));
+                        const float rmax_ = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(rx0, rx1), __builtin_fmaxf(ry0, ry1)), __builtin_fmaxf(rz0, rz1));
+                        le = __builtin_fmaxf(lmin, 0.0f);
+                        re = __builtin_fmaxf(rmin_, 0.0f);
+                        hl = le <= (CULL ? __builtin_fminf(lmax, t_far) : lmax);
+                        hr = re <= (CULL ? __builtin_fminf(rmax_, t_far) : rmax_);
+                        c0 = qb.z;
+                        c1 = qb.w;
+                        } else {
+                        const float4* __restrict__ nd = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.trav) + ((is_leaf ? 0u : t_ref) << 6));
+                        const float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
+                        hl = intersects_aabb_finite(o, aux, n0, n1);
+                        hr = intersects_aabb_finite(o, aux, n2, n3);
+                        c0 = __float_as_uint(n0.w);
+                        c1 = __float_as_uint(n1.w);
+                        }
+                        hl = hl && !is_leaf;
+                        hr = hr && !is_leaf;
+                        const bool both = hl && hr, any = hl || hr;
+                        const bool swp = CULL && both && re < le;                 // nearer child first
+                        const uint32_t cl = swp ? c1 : c0, cr = swp ? c0 : c1;
+                        lstack[t_sp * BLOCK + tid] = cr;                          // the next free slot, pushed or not
+                        const bool can = t_cnt < ML, app = is_leaf && can, stall = is_leaf && !can;
+                        if (app) {
+                            if (p.list16) lc16[t_cnt * BLOCK + tid16] = (uint16_t)t_ref;
+                            else lc32[t_cnt * BLOCK + tid] = t_ref & ~LEAF_BIT;
+                        }
+                        t_cnt += app ? 1u : 0u;
+                        n_cand += app ? 1u : 0u;
+                        const bool pop_ = !any && !stall, empty = t_sp == 0;
+                        t_ref = stall ? t_ref : any ? (hl ? cl : cr) : top;
+                        in_trav = !(pop_ && empty);
+                        t_sp = t_sp + (both ? 1u : 0u) - ((pop_ && !empty) ? 1u : 0u);
+                    }
+                } else
 #ifdef RT_ROLL_STEPS
 #pragma clang loop unroll(disable)
 #else
