@@ -1130,7 +1130,7 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 7 ? R
                 // hot line) and fails both tests, so it appends and pops; a full list stalls the lane until the flush between
                 // blocks; the right child is stored to the free stack slot pushed or not.  Taken when every walking lane of the
                 // wave carries its ray in grid units; a wave with a fallback lane runs the step below.
-                constexpr bool BF2 = (RT_BF2 != 0) && (ISECT == 2 || ISECT == 3 || ISECT == 7);
+                constexpr bool BF2 = (RT_BF2 != 0) && (ISECT == 2 || QNODES);
                 if (BF2 && !__ballot(in_trav && !(QNODES ? qfin : aux.finite))) {
 #pragma unroll
                     for (int rep = 0; rep < (QNODES ? RT_STEPS_PER_CHECK_Q : RT_STEPS_PER_CHECK_X); rep++)
@@ -1139,7 +1139,9 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 7 ? R
                         LCOUNT(5);
                         const bool is_leaf = (t_ref & LEAF_BIT) != 0;
                         if (STATS) n_int += is_leaf ? 0u : 1u;
-                        const uint32_t top = lstack[(t_sp - (t_sp ? 1u : 0u)) * BLOCK + tid];   // what a pop would yield
+                        // what a pop would yield (capped stack: entries from p.stack_lds up live in HBM, fetched below when needed)
+                        const uint32_t tsl = t_sp - (t_sp ? 1u : 0u);
+                        uint32_t top = lstack[(CAPPED ? min(tsl, p.stack_lds - 1u) : tsl) * BLOCK + tid];
                         bool hl, hr;
                         float le = 0.f, re = 0.f;
                         uint32_t c0, c1;                                            // left, right child reference
@@ -1178,7 +1180,8 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 7 ? R
                         const bool both = hl && hr, any = hl || hr;
                         const bool swp = CULL && both && re < le;                 // nearer child first
                         const uint32_t cl = swp ? c1 : c0, cr = swp ? c0 : c1;
-                        lstack[t_sp * BLOCK + tid] = cr;                          // the next free slot, pushed or not
+                        if (!CAPPED || t_sp < p.stack_lds) lstack[t_sp * BLOCK + tid] = cr;       // the next free slot, pushed or not
+                        else if (both) p.stack_ovf[(size_t)(t_sp - p.stack_lds) * p.ovf_stride + (blockIdx.x * BLOCK + tid)] = cr;
                         const bool can = t_cnt < ML, app = is_leaf && can, stall = is_leaf && !can;
                         if (app) {
                             if (p.list16) lc16[t_cnt * BLOCK + tid16] = (uint16_t)t_ref;
@@ -1187,6 +1190,8 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 7 ? R
                         t_cnt += app ? 1u : 0u;
                         n_cand += app ? 1u : 0u;
                         const bool pop_ = !any && !stall, empty = t_sp == 0;
+                        if (CAPPED && pop_ && t_sp > p.stack_lds)
+                            top = p.stack_ovf[(size_t)(t_sp - 1u - p.stack_lds) * p.ovf_stride + (blockIdx.x * BLOCK + tid)];
                         t_ref = stall ? t_ref : any ? (hl ? cl : cr) : top;
                         in_trav = !(pop_ && empty);
                         t_sp = t_sp + (both ? 1u : 0u) - ((pop_ && !empty) ? 1u : 0u);
