@@ -1197,7 +1197,8 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 7 ? R
                         t_sp = t_sp + (both ? 1u : 0u) - ((pop_ && !empty) ? 1u : 0u);
                     }
                 } else
-#ifdef RT_ROLL_STEPS
+                // (the step of a wave with a fallback lane: rare, kept rolled when the straight-line step is compiled in)
+#if defined(RT_ROLL_STEPS) || RT_BF2
 #pragma clang loop unroll(disable)
 #else
 #pragma unroll
