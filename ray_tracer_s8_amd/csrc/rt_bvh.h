@@ -53,9 +53,11 @@ struct TravNode {
 
 // Quantised traversal node (32 bytes = two uint4): the same topology as TravNode, child boxes rounded OUTWARDS onto
 // a 16-bit grid over the scene box (coordinate = base + q*step) with at least one whole grid unit of slack.  Only a conservative pre-filter: the
-// kernel validates every leaf it reaches with the exact box.
+// kernel validates every leaf it reaches with the exact box.  A box is held as CENTRE and HALF-EXTENT per axis (integers, lo = c - h,
+// hi = c + h, the upper plane at most one more unit out): the kernel then gets the near / far slab values as tc -+ h |ig| with
+// three fused multiply-adds per axis and child, and no min / max per plane (rt_kernel.hip.h).
 struct QNode {
-    uint16_t l_lo[3], l_hi[3], r_lo[3], r_hi[3];
+    uint16_t l_c[3], l_h[3], r_c[3], r_h[3];
     uint32_t left, right;
 };
 
@@ -354,10 +356,16 @@ inline FlatBVH build(const std::vector<Box>& prim) {
                 const TravNode& tn = out.trav[n];
                 QNode& qn = out.travq[n];
                 for (int a = 0; a < 3; a++) {
-                    qn.l_lo[a] = q_lo(tn.l_lo[a], a, g.ok);
-                    qn.l_hi[a] = q_hi(tn.l_hi[a], a, g.ok);
-                    qn.r_lo[a] = q_lo(tn.r_lo[a], a, g.ok);
-                    qn.r_hi[a] = q_hi(tn.r_hi[a], a, g.ok);
+                    // centre / half-extent: h = ceil((hi - lo) / 2), c = lo + h, so that c - h = lo and c + h = hi or hi + 1
+                    auto put = [&](float flo, float fhi, uint16_t& c, uint16_t& h) {
+                        const uint32_t lo = q_lo(flo, a, g.ok), hi = q_hi(fhi, a, g.ok);
+                        const uint32_t hh = hi >= lo ? (hi - lo + 1u) >> 1 : 0u;
+                        if (lo + hh > 65535u) g.ok = false;
+                        h = (uint16_t)hh;
+                        c = (uint16_t)(lo + hh);
+                    };
+                    put(tn.l_lo[a], tn.l_hi[a], qn.l_c[a], qn.l_h[a]);
+                    put(tn.r_lo[a], tn.r_hi[a], qn.r_c[a], qn.r_h[a]);
                 }
                 qn.left = tn.left;
                 qn.right = tn.right;

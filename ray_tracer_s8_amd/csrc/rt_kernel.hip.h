@@ -462,6 +462,26 @@ __device__ __forceinline__ const T& at32(const T* __restrict__ base, uint32_t i)
     return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + i * (uint32_t)sizeof(T));
 }
 
+// Slab values of the two child boxes of a QNode (rt_bvh.h: centre c and half-extent h per axis, 16-bit grid units) for a ray
+// carried in grid units, t(q) = q * ig + cq: per axis and child tc = fma(c, ig, cq) is the slab centre and
+// near / far = tc -+ h |ig| — whichever the sign of the direction — so the slab test needs no min / max per plane: three
+// fused multiply-adds (|ig| and -h are operand modifiers) instead of two and two min / max, which cost twice a fused
+// multiply-add each on this chip.  Real values up to < 0.2 grid unit of rounding (tc as before < 0.15, one more rounding
+// of a value below 2^18 + 2^16 units), against >= 1 unit of outward slack in the node: conservative.
+__device__ __forceinline__ void qslabs(const uint4 qa, const uint4 qb, V3 ig, V3 cq, float& lmin, float& lmax, float& rmin_, float& rmax_) {
+#define RT_Q(word, hi16) ((float)((hi16) ? ((word) >> 16) : ((word) & 0xffffu)))
+    const float ax = __builtin_fabsf(ig.x), ay = __builtin_fabsf(ig.y), az = __builtin_fabsf(ig.z);
+    const float lcx = __builtin_fmaf(RT_Q(qa.x, 0), ig.x, cq.x), lcy = __builtin_fmaf(RT_Q(qa.x, 1), ig.y, cq.y), lcz = __builtin_fmaf(RT_Q(qa.y, 0), ig.z, cq.z);
+    const float lhx = RT_Q(qa.y, 1), lhy = RT_Q(qa.z, 0), lhz = RT_Q(qa.z, 1);
+    const float rcx = __builtin_fmaf(RT_Q(qa.w, 0), ig.x, cq.x), rcy = __builtin_fmaf(RT_Q(qa.w, 1), ig.y, cq.y), rcz = __builtin_fmaf(RT_Q(qb.x, 0), ig.z, cq.z);
+    const float rhx = RT_Q(qb.x, 1), rhy = RT_Q(qb.y, 0), rhz = RT_Q(qb.y, 1);
+#undef RT_Q
+    lmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(-lhx, ax, lcx), __builtin_fmaf(-lhy, ay, lcy)), __builtin_fmaf(-lhz, az, lcz));
+    lmax = __builtin_fminf(__builtin_fminf(__builtin_fmaf(lhx, ax, lcx), __builtin_fmaf(lhy, ay, lcy)), __builtin_fmaf(lhz, az, lcz));
+    rmin_ = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(-rhx, ax, rcx), __builtin_fmaf(-rhy, ay, rcy)), __builtin_fmaf(-rhz, az, rcz));
+    rmax_ = __builtin_fminf(__builtin_fminf(__builtin_fmaf(rhx, ax, rcx), __builtin_fmaf(rhy, ay, rcy)), __builtin_fmaf(rhz, az, rcz));
+}
+
 // Distance culling bound of the culled walk (ISECT 7).  A sphere X whose own AABB the ray enters at t_X
 // and whose reference root test returns x satisfies x >= t_X - sqrt(2) r_X - 2^-9 |o - c_X| - 2^-21.4 |o - c_X|^2 (genuine
 // roots lie in the box up to the rounding of the reference's quadratic; false roots of a near miss lie within 2^-9 |oc| of
@@ -1149,18 +1169,8 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 7 ? R
                         const uint4* __restrict__ nq = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.travq) + ((is_leaf ? 0u : t_ref) << 5));
                         uint4 qa = nq[0], qb = nq[1];
                         asm volatile("" : "+v"(qb.x), "+v"(qb.y), "+v"(qb.z), "+v"(qb.w));   // keep the two 16-byte loads whole
-#define RT_Q(word, hi16) ((float)((hi16) ? ((word) >> 16) : ((word) & 0xffffu)))
-                        const float lx0 = __builtin_fmaf(RT_Q(qa.x, 0), ig.x, cq.x), lx1 = __builtin_fmaf(RT_Q(qa.y, 1), ig.x, cq.x);
-                        const float ly0 = __builtin_fmaf(RT_Q(qa.x, 1), ig.y, cq.y), ly1 = __builtin_fmaf(RT_Q(qa.z, 0), ig.y, cq.y);
-                        const float lz0 = __builtin_fmaf(RT_Q(qa.y, 0), ig.z, cq.z), lz1 = __builtin_fmaf(RT_Q(qa.z, 1), ig.z, cq.z);
-                        const float rx0 = __builtin_fmaf(RT_Q(qa.w, 0), ig.x, cq.x), rx1 = __builtin_fmaf(RT_Q(qb.x, 1), ig.x, cq.x);
-                        const float ry0 = __builtin_fmaf(RT_Q(qa.w, 1), ig.y, cq.y), ry1 = __builtin_fmaf(RT_Q(qb.y, 0), ig.y, cq.y);
-                        const float rz0 = __builtin_fmaf(RT_Q(qb.x, 0), ig.z, cq.z), rz1 = __builtin_fmaf(RT_Q(qb.y, 1), ig.z, cq.z);
-#undef RT_Q
-                        const float lmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(lx0, lx1), __builtin_fminf(ly0, ly1)), __builtin_fminf(lz0, lz1));
-                        const float lmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(lx0, lx1), __builtin_fmaxf(ly0, ly1)), __builtin_fmaxf(lz0, lz1));
-                        const float rmin_ = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(rx0, rx1), __builtin_fminf(ry0, ry1)), __builtin_fminf(rz0, rz1));
-                        const float rmax_ = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(rx0, rx1), __builtin_fmaxf(ry0, ry1)), __builtin_fmaxf(rz0, rz1));
+                        float lmin, lmax, rmin_, rmax_;
+                        qslabs(qa, qb, ig, cq, lmin, lmax, rmin_, rmax_);
                         le = __builtin_fmaxf(lmin, 0.0f);
                         re = __builtin_fmaxf(rmin_, 0.0f);
                         hl = le <= (CULL ? __builtin_fminf(lmax, t_far) : lmax);
@@ -1254,22 +1264,8 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 7 ? R
                                 // slab test in grid units: t = fma(q, ig, cq), the same real value as
                                 // ((base + q*step) - o) * inv up to < 0.15 grid unit of rounding; the boxes carry >= 1 grid
                                 // unit of outward slack: conservative, exactness restored at the leaves
-#define RT_Q(word, hi16) ((float)((hi16) ? ((word) >> 16) : ((word) & 0xffffu)))
-                                const float lx0 = __builtin_fmaf(RT_Q(qa.x, 0), ig.x, cq.x), lx1 = __builtin_fmaf(RT_Q(qa.y, 1), ig.x, cq.x);
-                                const float ly0 = __builtin_fmaf(RT_Q(qa.x, 1), ig.y, cq.y), ly1 = __builtin_fmaf(RT_Q(qa.z, 0), ig.y, cq.y);
-                                const float lz0 = __builtin_fmaf(RT_Q(qa.y, 0), ig.z, cq.z), lz1 = __builtin_fmaf(RT_Q(qa.z, 1), ig.z, cq.z);
-                                const float rx0 = __builtin_fmaf(RT_Q(qa.w, 0), ig.x, cq.x), rx1 = __builtin_fmaf(RT_Q(qb.x, 1), ig.x, cq.x);
-                                const float ry0 = __builtin_fmaf(RT_Q(qa.w, 1), ig.y, cq.y), ry1 = __builtin_fmaf(RT_Q(qb.y, 0), ig.y, cq.y);
-                                const float rz0 = __builtin_fmaf(RT_Q(qb.x, 0), ig.z, cq.z), rz1 = __builtin_fmaf(RT_Q(qb.y, 1), ig.z, cq.z);
-#undef RT_Q
-                                const float lmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(lx0, lx1), __builtin_fminf(ly0, ly1)),
-                                                                   __builtin_fminf(lz0, lz1));
-                                const float lmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(lx0, lx1), __builtin_fmaxf(ly0, ly1)),
-                                                                   __builtin_fmaxf(lz0, lz1));
-                                const float rmin_ = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(rx0, rx1), __builtin_fminf(ry0, ry1)),
-                                                                    __builtin_fminf(rz0, rz1));
-                                const float rmax_ = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(rx0, rx1), __builtin_fmaxf(ry0, ry1)),
-                                                                    __builtin_fmaxf(rz0, rz1));
+                                float lmin, lmax, rmin_, rmax_;
+                                qslabs(qa, qb, ig, cq, lmin, lmax, rmin_, rmax_);
                                 if (CULL) {
                                     // the exit clipped to t_far: a box entered beyond it is skipped; the nearer child first
                                     const float le = __builtin_fmaxf(lmin, 0.0f), re = __builtin_fmaxf(rmin_, 0.0f);

@@ -88,7 +88,7 @@ int host_bvh_traverse(const float* boxes, uint32_t n, const float* origin, const
 
 // Structure checks of the flat tree and its quantised twin.  Returns 0 when every check holds, else a code:
 // 1 node count, 2 leaf_of not the depth-first rank, 3 parent links / own boxes, 4 quantised topology, 5 a quantised
-// box with less than one grid unit of outward slack, 6 more than four units (needlessly loose), 7 depth.
+// box with less than one grid unit of outward slack, 6 more than four (upper plane: five) units (needlessly loose), 7 depth.
 // out[0] = internal nodes, out[1] = grid ok (0/1), out[2] = depth.
 int host_bvh_check(const float* boxes, uint32_t n, uint32_t* out) {
     const std::vector<rtbvh::Box> prim = to_boxes(boxes, n);
@@ -145,14 +145,16 @@ int host_bvh_check(const float* boxes, uint32_t n, uint32_t* out) {
         if (q.left != e.left || q.right != e.right) return 4;
         const float* elo[2] = {e.l_lo, e.r_lo};
         const float* ehi[2] = {e.l_hi, e.r_hi};
-        const uint16_t* qlo[2] = {q.l_lo, q.r_lo};
-        const uint16_t* qhi[2] = {q.l_hi, q.r_hi};
+        const uint16_t* qc[2] = {q.l_c, q.r_c};
+        const uint16_t* qh[2] = {q.l_h, q.r_h};
         for (int c = 0; c < 2; c++)
             for (int a = 0; a < 3; a++) {
+                // centre / half-extent form: lo = c - h, hi = c + h (the upper plane may sit one more unit out)
+                if (qh[c][a] > qc[c][a]) return 5;
                 const double st = t.grid.step[a], base = t.grid.base[a];
-                const double lo = base + st * qlo[c][a], hi = base + st * qhi[c][a];
+                const double lo = base + st * ((double)qc[c][a] - (double)qh[c][a]), hi = base + st * ((double)qc[c][a] + (double)qh[c][a]);
                 if (!(lo <= (double)elo[c][a] - st) || !(hi >= (double)ehi[c][a] + st)) return 5;
-                if (!(lo >= (double)elo[c][a] - 4.0 * st) || !(hi <= (double)ehi[c][a] + 4.0 * st)) return 6;
+                if (!(lo >= (double)elo[c][a] - 4.0 * st) || !(hi <= (double)ehi[c][a] + 5.0 * st)) return 6;
             }
     }
     return 0;
