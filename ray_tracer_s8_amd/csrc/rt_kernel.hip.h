@@ -364,7 +364,8 @@ __device__ __forceinline__ bool bvh_reaches(const float4* __restrict__ nodes, ui
 struct Hit {
     int idx;
     float dist;
-    V3 p;
+    float t;       // the root; the hit point is formed again where it is used, P = o + t * d (Ray::at): the same operation on
+                   // the same operands gives the same bits, and the walk carries one register instead of three
 };
 // MODE 0: plain index order (RT_FLAG_NO_BVH_CULL).  MODE 1: BVH semantics, chain validation deferred
 // to the winner (ties still go to the earlier DFS leaf).  MODE 2: BVH semantics, every improving hit is
@@ -388,7 +389,7 @@ __device__ __forceinline__ void consider(Hit& h, int idx, V3 o, V3 d, float t, c
     }
     h.idx = idx;
     h.dist = dist;
-    h.p = p;
+    h.t = t;
 }
 
 // index-order first minimum over the primitives that satisfy `admitted` (evaluated only for an improving hit)
@@ -403,7 +404,7 @@ __device__ __forceinline__ void consider_if(Hit& h, int idx, V3 o, V3 d, float t
     if (!admitted()) return;
     h.idx = idx;
     h.dist = dist;
-    h.p = p;
+    h.t = t;
 }
 
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
@@ -612,8 +613,13 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 7 ? R
     Hit h;
     h.idx = -1;
     h.dist = 0.f;
-    h.p = mk(0, 0, 0);
+    h.t = 0.f;
     RayAux aux = ray_aux(mk(1.f, 1.f, 1.f), false);
+    // The quantised walks carry the ray in grid units and need the inverse direction only where a leaf is validated or a
+    // fallback lane walks the exact nodes: it is formed again there (three divisions) instead of living in three
+    // registers across the walk (the culled kernel spilled seven registers without this, which showed as 2.5 x the
+    // fetch traffic past L2).
+    auto AUX = [&]() -> RayAux { return QNODES ? ray_aux(d, (p.flags & 8u) != 0) : aux; };
     V3 td = mk(0, 0, 0);                     // linear engines: 2 * d of the current segment
     bool in_trav = false;
     uint32_t t_ref = 0, t_sp = 0, t_cnt = 0;
@@ -872,7 +878,7 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 7 ? R
                     const float4 g = at32(p.geom, prim);
                     float t;
                     if (exact_sphere(o, 2.0f * d, mk(g.x, g.y, g.z), g.w, p.t_min, p.t_max, t))
-                        consider_if<true>(h, (int)prim, o, d, t, [&]() { return bvh_reaches(p.bvh_nodes, p.leaf_of[prim], o, aux); }, p.leaf_of);
+                        consider_if<true>(h, (int)prim, o, d, t, [&]() { return bvh_reaches(p.bvh_nodes, p.leaf_of[prim], o, AUX()); }, p.leaf_of);
                 }
                 if (h.idx >= 0) t_far = cull_bound(h.dist, o, p.r_slack);
             }
@@ -910,7 +916,7 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 7 ? R
                                 consider_if<CULL>(h, (int)prim, o, d, t, [&]() {
                                     if (!qfin || (p.n_sph + p.n_tri) == 1) return true;
                                     const float4 s = at32(p.geom_r, prim);
-                                    return intersects_aabb_finite(o, aux, make_float4(s.x - s.w, s.y - s.w, s.z - s.w, 0.f),
+                                    return intersects_aabb_finite(o, AUX(), make_float4(s.x - s.w, s.y - s.w, s.z - s.w, 0.f),
                                                                   make_float4(s.x + s.w, s.y + s.w, s.z + s.w, 0.f));
                                 }, p.leaf_of);
                             else
@@ -920,7 +926,7 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 7 ? R
                         if (exact_triangle(o, d, p.tri + 9 * (size_t)(prim - p.n_sph), p.t_min, p.t_max, t)) {
                             if (QNODES)
                                 consider_if(h, (int)prim, o, d, t,
-                                            [&]() { return !qfin || bvh_reaches(p.bvh_nodes, p.leaf_of[prim], o, aux); });
+                                            [&]() { return !qfin || bvh_reaches(p.bvh_nodes, p.leaf_of[prim], o, AUX()); });
                             else
                                 consider<0>(h, (int)prim, o, d, t, aux, p.bvh_nodes, p.leaf_of);
                         }
@@ -1017,7 +1023,7 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 7 ? R
                 }
                 if (best_k >= 0) {
                     h.idx = (int)(p.list16 ? (uint32_t)lc16[(uint32_t)best_k * BLOCK + tid16] : lc32[(uint32_t)best_k * BLOCK + tid]);
-                    h.p = o + best_t * d;
+                    h.t = best_t;
                 }
                 if (want) t_cnt = 0;
             };
@@ -1284,8 +1290,9 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 7 ? R
                                 // +-0 direction component (inverse = +-inf): the monotonicity argument does not hold, so
                                 // this lane walks the exact nodes with the crate's literal test; its leaves need no validation
                                 const float4* __restrict__ nd = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.trav) + (t_ref << 6));
-                                hl = intersects_aabb(o, aux, nd[0], nd[1]);
-                                hr = intersects_aabb(o, aux, nd[2], nd[3]);
+                                const RayAux ax = AUX();
+                                hl = intersects_aabb(o, ax, nd[0], nd[1]);
+                                hr = intersects_aabb(o, ax, nd[2], nd[3]);
                             }
                         } else {
                             const float4* __restrict__ nd = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.trav) + (t_ref << 6));
@@ -1496,9 +1503,10 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 7 ? R
                     finished = true;
                 } else {
                     V3 n;
+                    const V3 hp = o + h.t * d;                                       // Ray::at (ray.rs:147-149), as in consider
                     if ((uint32_t)h.idx < p.n_sph) {
                         float4 g = at32(p.geom, (uint32_t)h.idx);
-                        n = normalize_or_zero(h.p - mk(g.x, g.y, g.z));             // sphere.rs:49-51
+                        n = normalize_or_zero(hp - mk(g.x, g.y, g.z));               // sphere.rs:49-51
                     } else {
                         const float* tv = p.tri + 9 * (size_t)(h.idx - p.n_sph);
                         V3 A = mk(tv[0], tv[1], tv[2]), B = mk(tv[3], tv[4], tv[5]), C = mk(tv[6], tv[7], tv[8]);
@@ -1523,7 +1531,7 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 7 ? R
                         }
                     } else {
                         // scattered ray: generated at the top of the next round together with the camera rays
-                        o = h.p;                                                       // origin exactly P
+                        o = hp;                                                        // origin exactly P
                         bn = n;
                         brough = m.w;
                         bounce = true;
