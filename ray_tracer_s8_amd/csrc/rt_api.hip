@@ -113,6 +113,7 @@ struct rt_scene {
     uint32_t n_big = 0;
     float r_slack = 0.f;           //   largest radius among the other spheres
     bool cull_pays = false;        //   host heuristic: the scene is dense enough for the culled walk (build_host_scene)
+    bool inverted_boxes = false;   // a sphere of negative radius: its AABB has lo > hi (sphere.rs:65-72), see launch_batch
     float cull_density = 0.f;      //   the box density behind it
     rtbvh::QGrid grid;
     float leaf_density = 0.f;      // sum of primitive box areas / scene box area (node-format heuristic)
@@ -215,6 +216,11 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     p.n_sph_pad = sc->n_sph_pad;
     p.n_tri = sc->n_tri;
     p.flags = rq->flags;
+    // A sphere of negative radius has an AABB with lo > hi (Sphere::aabb = center -+ radius, sphere.rs:65-72): the reference's
+    // sign-selected slab test rejects such a box for (almost) every ray, while the finite-direction shortcut of the kernels
+    // (min / max of the two plane values, valid for lo <= hi) would enter it.  Such a scene is rendered with the crate's
+    // literal test and the whole box chain throughout (the RT_FLAG_FULL_CHAIN path): slower, and exact.
+    if (sc->inverted_boxes) p.flags |= RT_FLAG_FULL_CHAIN;
     // Engine choice.  BVH traversal reproduces reference semantics only, needs the tree to fit the traversal
     // stack, and pays off once the scene is larger than a couple of LDS chunks; RT_FLAG_BVH_TRAVERSE /
     // RT_FLAG_LINEAR_SCAN force either engine for A/B runs and tests.
@@ -604,6 +610,7 @@ struct HostScene {
     uint32_t n_big = 0;
     float r_slack = 0.f;             // ... the largest radius among the others
     bool cull_pays = false;          // enough of the rays hit something for nearer-first + culling to beat the plain walk
+    bool inverted_boxes = false;     // some sphere has a negative radius
     float cull_density = 0.f;        // sum of the other spheres' box areas / area of the box around them
 };
 
@@ -753,7 +760,10 @@ static void build_host_scene(const rt_sphere* sp, uint32_t ns, const rt_triangle
         hs.leaf_density = root > 0.0 ? (float)(area / root) : INFINITY;
     }
     hs.geom_r.assign(ns ? ns : 1, make_float4(0.f, 0.f, 0.f, 0.f));
-    for (uint32_t i = 0; i < ns; i++) hs.geom_r[i] = make_float4(sp[i].cx, sp[i].cy, sp[i].cz, sp[i].radius);
+    for (uint32_t i = 0; i < ns; i++) {
+        hs.geom_r[i] = make_float4(sp[i].cx, sp[i].cy, sp[i].cz, sp[i].radius);
+        if (sp[i].radius < 0.0f) hs.inverted_boxes = true;
+    }
     // culled walk: its distance bound carries sqrt(2) * (largest radius) of slack, so the few spheres far larger than the
     // rest (a ground sphere) are listed apart and root-tested at every query start instead
     {
@@ -874,6 +884,7 @@ static int upload_scene(int device, const HostScene& hs, rt_scene** out) {
     sc->n_big = hs.n_big;
     sc->r_slack = hs.r_slack;
     sc->cull_pays = hs.cull_pays;
+    sc->inverted_boxes = hs.inverted_boxes;
     sc->cull_density = hs.cull_density;
     SC_CHK(hipMalloc(&sc->d_counters, COUNTER_WORDS * sizeof(unsigned long long)));
     SC_CHK(hipMemsetAsync(sc->d_counters, 0, COUNTER_WORDS * sizeof(unsigned long long), ctx->stream));

@@ -699,3 +699,47 @@ def test_concurrent_host_threads_share_device_and_scene(ndev):
         t.join()
     shared.close()
     assert not errors, errors
+
+
+@pytest.mark.parametrize("kind", ["many_big", "camera_inside", "odd_radii", "equal_spheres"])
+def test_culled_walk_odd_scenes(ndev, oracle, kind):
+    """Scenes that stress the culled walk's side conditions (all forced through it, and through the plain quantised walk):
+    more large spheres than its 'big' list holds (the slack radius becomes large: little is culled, nothing may be lost),
+    a camera inside a pile of overlapping spheres (box entry distances of zero), zero / negative / tiny radii, and many
+    coincident equal spheres (exact distance ties between candidates that arrive out of depth-first order)."""
+    g = np.random.default_rng({"many_big": 1, "camera_inside": 2, "odd_radii": 3, "equal_spheres": 4}[kind])
+    n = 3000
+    sph = np.zeros(n, _abi.SPHERE_DTYPE)
+    sph["cx"], sph["cy"], sph["cz"] = g.uniform(-30, 30, n), g.uniform(-2, 12, n), g.uniform(-70, -4, n)
+    sph["radius"] = g.uniform(0.1, 0.5, n)
+    if kind == "many_big":
+        big = g.choice(n, 40, replace=False)
+        sph["radius"][big] = g.uniform(8.0, 30.0, 40)
+        sph["cy"][big] = -40.0
+    elif kind == "camera_inside":
+        sph["cx"], sph["cy"], sph["cz"] = g.uniform(-3, 3, n), g.uniform(-3, 3, n), g.uniform(-8, 2, n)
+        sph["radius"] = g.uniform(0.3, 1.2, n)
+    elif kind == "odd_radii":
+        sph["radius"][:300] = 0.0
+        sph["radius"][300:600] = -g.uniform(0.1, 0.5, 300)
+        sph["radius"][600:900] = 1e-6
+    else:
+        sph["cx"][:1500], sph["cy"][:1500], sph["cz"][:1500] = sph["cx"][1500:], sph["cy"][1500:], sph["cz"][1500:]
+        sph["radius"][:1500] = sph["radius"][1500:]
+    for c in ("albedo_r", "albedo_g", "albedo_b"):
+        sph[c] = g.uniform(0.2, 0.9, n)
+    sph["roughness"] = g.choice([0.0, 0.5, 1.0], n)
+    sph["emission"] = np.where(g.uniform(size=n) < 0.02, 4.0, 0.0)
+    rq = _abi.default_request(width=160, height=90, divisions=1, spp=3, max_bounces=6, seed=31)
+    base = _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_QUANT_NODES
+    a = _compare(oracle, rq, sph, flags=base | _abi.RT_FLAG_CULL_WALK)
+    b = _compare(oracle, rq, sph, flags=base | _abi.RT_FLAG_NO_CULL_WALK)
+    assert a.ray_segments == b.ray_segments
+    if a.engine in (3, 5):                               # (a grid too coarse for the scene falls back to the exact nodes)
+        assert a.engine == 5 and b.engine == 3 and a.broad_candidates <= b.broad_candidates
+    # the other engines on the same scene, and the LDS-resident tree on a part of it.  (A sphere of negative radius has an
+    # AABB with lo > hi, which the reference's sign-selected slab test rejects: the exact-node L2 walk once entered it.)
+    c = _compare(oracle, rq, sph, flags=_abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_EXACT_NODES | _abi.RT_FLAG_NO_LDS_TREE)
+    d = _compare(oracle, rq, sph, flags=_abi.RT_FLAG_LINEAR_SCAN)
+    e = _compare(oracle, rq, sph[:900] if kind != "odd_radii" else np.concatenate([sph[200:500], sph[900:1400]]), flags=0)
+    assert c.engine == 2 and d.engine in (0, 1) and e.engine == 4
