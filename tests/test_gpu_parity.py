@@ -743,3 +743,93 @@ def test_culled_walk_odd_scenes(ndev, oracle, kind):
     d = _compare(oracle, rq, sph, flags=_abi.RT_FLAG_LINEAR_SCAN)
     e = _compare(oracle, rq, sph[:900] if kind != "odd_radii" else np.concatenate([sph[200:500], sph[900:1400]]), flags=0)
     assert c.engine == 2 and d.engine in (0, 1) and e.engine == 4
+
+
+_EXTREME = {
+    "tiny_fov": dict(fov=1e-3), "wide_fov": dict(fov=3.1), "huge_aperture": dict(aperture=8.0, focus_distance=12.0),
+    "zero_focus": dict(focus_distance=0.0), "negative_focal": dict(focal_length=-1.0), "t_min_zero": dict(t_min=0.0),
+    "t_min_negative": dict(t_min=-5.0), "t_window_empty": dict(t_min=10.0, t_max=5.0), "t_max_tiny": dict(t_max=0.01),
+    "seed_all_ones": dict(seed=0xFFFFFFFFFFFFFFFF), "seed_zero": dict(seed=0), "one_row_strips": dict(divisions=54, division_no=53),
+    "single_sample": dict(spp=1, max_bounces=1),
+}
+
+
+@pytest.mark.parametrize("case", sorted(_EXTREME))
+def test_extreme_knobs_and_materials(ndev, oracle, case):
+    """Request knobs at and beyond the edges of what a camera means (the reference does not validate them either), and
+    materials outside [0, 1] (albedo > 1, negative emission, roughness 2 and -1): same bits as the oracle in the linear engine,
+    the LDS-resident tree, the exact and the quantised L2 walks."""
+    g = np.random.default_rng(17)
+    n = 300
+    sph = np.zeros(n, _abi.SPHERE_DTYPE)
+    sph["cx"], sph["cy"], sph["cz"] = g.uniform(-8, 8, n), g.uniform(-3, 5, n), g.uniform(-20, -2, n)
+    sph["radius"] = g.uniform(0.2, 0.9, n)
+    sph["cx"][0], sph["cy"][0], sph["cz"][0], sph["radius"][0] = 0.0, -203.0, -10.0, 200.0
+    sph["albedo_r"], sph["albedo_g"], sph["albedo_b"] = g.uniform(0.0, 1.6, n), g.uniform(0.0, 1.0, n), g.uniform(0.0, 1.2, n)
+    sph["roughness"] = g.choice([0.0, 0.3, 1.0, 2.0, -1.0], n)
+    sph["emission"] = np.where(g.uniform(size=n) < 0.1, g.choice([3.0, -2.0, 0.0, 1e-30], n), 0.0)
+    kw = dict(width=120, height=54, divisions=2, division_no=1, spp=2, max_bounces=5, seed=5)
+    kw.update(_EXTREME[case])
+    rq = _abi.default_request(**kw)
+    for flags in (_abi.RT_FLAG_LINEAR_SCAN, 0, _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_EXACT_NODES | _abi.RT_FLAG_NO_LDS_TREE,
+                  _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_QUANT_NODES):
+        _compare(oracle, rq, sph, flags=flags)
+
+
+def test_wide_image_and_far_camera_scene(ndev, oracle):
+    """A strip wider than 65 535 pixels (pixel columns beyond 16 bits, tiles_x > 1024), and a scene far from the origin with a
+    large common offset (the cancellation regime of the expanded broad phase and of the grid form of the quantised walk)."""
+    sph = scenes.cornell16()
+    rq = _abi.default_request(width=70001, height=2, divisions=2, division_no=1, spp=1, max_bounces=2, seed=77)
+    _compare(oracle, rq, sph)
+    g = np.random.default_rng(23)
+    n = 5000
+    far = np.zeros(n, _abi.SPHERE_DTYPE)
+    far["cx"], far["cy"], far["cz"] = g.uniform(-30, 30, n), g.uniform(-20, 20, n), -5000.0 + g.uniform(-60, -4, n)   # (the camera sits at the origin, looking down -z)
+    far["radius"] = g.uniform(0.1, 0.6, n)
+    for c in ("albedo_r", "albedo_g", "albedo_b"):
+        far[c] = g.uniform(0.2, 0.9, n)
+    far["roughness"] = g.choice([0.0, 1.0], n)
+    rq2 = _abi.default_request(width=96, height=64, divisions=1, spp=2, max_bounces=4, seed=8, fov=0.02, t_max=1e5)
+    for flags in (0, _abi.RT_FLAG_LINEAR_SCAN, _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_EXACT_NODES):
+        st = _compare(oracle, rq2, far, flags=flags)
+    assert st.ray_segments > rq2.width * rq2.height * rq2.spp          # the cluster is in view: some paths bounce
+
+
+def test_degenerate_and_axis_aligned_triangles(ndev, oracle):
+    """Triangles the reference does not reject: zero area (two equal vertices, three collinear ones), boxes of zero extent
+    along an axis (floor / wall quads) seen by rays that run inside their plane (pinhole camera at the plane's height: the
+    0 * inf slabs of ray.rs:174-194), one huge and many tiny triangles, with a few spheres; every engine."""
+    g = np.random.default_rng(41)
+    tris = []
+
+    def tri(a, b, c, alb=(0.7, 0.6, 0.5), rough=0.0, emis=0.0):
+        tris.append((a, b, c, alb[0], alb[1], alb[2], rough, emis))
+
+    tri((-6, 0, -2), (6, 0, -2), (6, 0, -14))                       # floor quad at the camera's height y = 0: rays with d.y = 0 lie in it
+    tri((-6, 0, -2), (6, 0, -14), (-6, 0, -14))
+    tri((-6, -3, -14), (6, -3, -14), (6, 5, -14), (0.3, 0.5, 0.8), 1.0)   # back wall z = -14 (mirror)
+    tri((-6, -3, -14), (6, 5, -14), (-6, 5, -14), (0.3, 0.5, 0.8), 1.0)
+    tri((0, -3, -2), (0, 5, -2), (0, 5, -14), (0.8, 0.3, 0.3))      # wall in the plane x = 0: contains the camera's optical axis
+    tri((1, 1, -5), (1, 1, -5), (2, 2, -6))                         # two equal vertices
+    tri((-2, 1, -5), (-1, 2, -6), (0, 3, -7))                       # collinear
+    tri((3, 3, -9), (3, 3, -9), (3, 3, -9))                         # a point
+    tri((-500, -4, 100), (500, -4, 100), (0, -4, -900), (0.5, 0.5, 0.5))  # huge
+    for _ in range(60):                                             # tiny ones
+        c = np.array([g.uniform(-4, 4), g.uniform(-2, 3), g.uniform(-12, -3)])
+        tri(tuple(c), tuple(c + g.uniform(-1e-3, 1e-3, 3)), tuple(c + g.uniform(-1e-3, 1e-3, 3)), (0.9, 0.9, 0.2), 0.0, 5.0)
+    for _ in range(40):
+        c = np.array([g.uniform(-4, 4), g.uniform(-2, 3), g.uniform(-12, -3)])
+        tri(tuple(c), tuple(c + g.uniform(-1, 1, 3)), tuple(c + g.uniform(-1, 1, 3)), tuple(g.uniform(0.2, 0.9, 3)), float(g.choice([0.0, 1.0])))
+    tr = np.array(tris, dtype=_abi.TRIANGLE_DTYPE)
+    sph = np.zeros(5, _abi.SPHERE_DTYPE)
+    sph["cx"], sph["cy"], sph["cz"], sph["radius"] = [-3, 3, 0, -1, 2], [1, 1, 2, -1, -2], [-6, -8, -10, -4, -5], [0.8, 0.6, 1.0, 0.4, 0.5]
+    sph["albedo_r"] = sph["albedo_g"] = sph["albedo_b"] = 0.8
+    sph["roughness"] = [0.0, 1.0, 0.5, 1.0, 0.0]
+    # odd image sizes put a pixel column / row on the optical axis; aperture 0 keeps those rays exactly axis-parallel
+    rq = _abi.default_request(width=97, height=65, divisions=1, spp=3, max_bounces=6, seed=13, aperture=0.0)
+    for flags in (0, _abi.RT_FLAG_LINEAR_SCAN, _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_EXACT_NODES | _abi.RT_FLAG_NO_LDS_TREE,
+                  _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_QUANT_NODES, _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_FULL_CHAIN,
+                  _abi.RT_FLAG_NO_BVH_CULL):
+        _compare(oracle, rq, sph, tr, flags=flags)
+    _compare(oracle, rq, None, tr, flags=0)                          # triangles only
