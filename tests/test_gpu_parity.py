@@ -833,3 +833,27 @@ def test_degenerate_and_axis_aligned_triangles(ndev, oracle):
                   _abi.RT_FLAG_NO_BVH_CULL):
         _compare(oracle, rq, sph, tr, flags=flags)
     _compare(oracle, rq, None, tr, flags=0)                          # triangles only
+
+
+@pytest.mark.parametrize("n", [700, 5000])
+def test_hundreds_of_candidates_per_ray(ndev, oracle, n):
+    """A pile of large overlapping spheres around the optical axis: every ray enters hundreds of leaf boxes, so the leaf lists
+    of the walks overflow all the time — the branch-free steps' stalled lanes, the flushes between blocks, the compacted root
+    tests with every lane's list full, the culled walk's early flushes.  n = 700 fits the LDS-resident tree, 5000 does not."""
+    g = np.random.default_rng(n)
+    sph = np.zeros(n, _abi.SPHERE_DTYPE)
+    sph["cx"], sph["cy"], sph["cz"] = g.normal(0, 1.5, n), g.normal(0, 1.5, n), -12.0 + g.normal(0, 3.0, n)
+    sph["radius"] = g.uniform(1.0, 4.0, n)
+    for c in ("albedo_r", "albedo_g", "albedo_b"):
+        sph[c] = g.uniform(0.3, 0.9, n)
+    sph["roughness"] = g.choice([0.0, 1.0], n)
+    rq = _abi.default_request(width=80, height=48, divisions=1, spp=2, max_bounces=4, seed=3)
+    engines = {}
+    for flags in (0, _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_EXACT_NODES | _abi.RT_FLAG_NO_LDS_TREE,
+                  _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_QUANT_NODES | _abi.RT_FLAG_NO_CULL_WALK,
+                  _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_QUANT_NODES | _abi.RT_FLAG_CULL_WALK, _abi.RT_FLAG_LINEAR_SCAN):
+        st = _compare(oracle, rq, sph, flags=flags)
+        engines[flags] = st.engine
+        if flags and not (flags & _abi.RT_FLAG_LINEAR_SCAN) and not (flags & _abi.RT_FLAG_CULL_WALK):
+            assert st.broad_candidates > 50 * st.ray_segments, st.broad_candidates / st.ray_segments
+    assert engines[0] in (2, 3, 4, 5)            # (whatever the host picks for such a pile: deep tree, large slack radius)
