@@ -837,7 +837,7 @@ def test_degenerate_and_axis_aligned_triangles(ndev, oracle):
 
 @pytest.mark.parametrize("n", [700, 5000])
 def test_hundreds_of_candidates_per_ray(ndev, oracle, n):
-    """A pile of large overlapping spheres around the optical axis: every ray enters hundreds of leaf boxes, so the leaf lists
+    """A pile of large overlapping spheres around the optical axis: every ray enters dozens to hundreds of leaf boxes, so the leaf lists
     of the walks overflow all the time — the branch-free steps' stalled lanes, the flushes between blocks, the compacted root
     tests with every lane's list full, the culled walk's early flushes.  n = 700 fits the LDS-resident tree, 5000 does not."""
     g = np.random.default_rng(n)
