@@ -857,3 +857,22 @@ def test_hundreds_of_candidates_per_ray(ndev, oracle, n):
         if flags and not (flags & _abi.RT_FLAG_LINEAR_SCAN) and not (flags & _abi.RT_FLAG_CULL_WALK):
             assert st.broad_candidates > 20 * st.ray_segments, st.broad_candidates / st.ray_segments
     assert engines[0] in (2, 3, 4, 5)            # (whatever the host picks for such a pile: deep tree, large slack radius)
+
+
+def test_thousands_of_identical_spheres(ndev, oracle):
+    """2 000 copies of one mirror sphere, 2 000 of a diffuse one and a ground: every hit is an exact distance tie between
+    thousands of candidates (the first leaf in depth-first order wins, shapes/mod.rs:177-182), the centroid bounds of the
+    build collapse (halving fallback, bvh_impl.rs), the tree is as deep as it gets for its size."""
+    sph = np.zeros(4001, _abi.SPHERE_DTYPE)
+    sph["cx"][:2000], sph["cy"][:2000], sph["cz"][:2000], sph["radius"][:2000] = -1.5, 0.5, -6.0, 1.5
+    sph["cx"][2000:4000], sph["cy"][2000:4000], sph["cz"][2000:4000], sph["radius"][2000:4000] = 1.8, 0.2, -5.0, 1.2
+    sph["cx"][4000], sph["cy"][4000], sph["cz"][4000], sph["radius"][4000] = 0.0, -101.0, -6.0, 100.0
+    g = np.random.default_rng(5)
+    for c in ("albedo_r", "albedo_g", "albedo_b"):
+        sph[c] = g.uniform(0.2, 0.95, 4001)                  # the copies differ in colour: the winner of a tie shows
+    sph["roughness"][:2000] = 1.0
+    rq = _abi.default_request(width=64, height=40, divisions=1, spp=2, max_bounces=3, seed=1)
+    for flags in (0, _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_EXACT_NODES | _abi.RT_FLAG_NO_LDS_TREE,
+                  _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_QUANT_NODES | _abi.RT_FLAG_NO_CULL_WALK,
+                  _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_QUANT_NODES | _abi.RT_FLAG_CULL_WALK, _abi.RT_FLAG_LINEAR_SCAN):
+        _compare(oracle, rq, sph, flags=flags)
