@@ -876,3 +876,19 @@ def test_thousands_of_identical_spheres(ndev, oracle):
                   _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_QUANT_NODES | _abi.RT_FLAG_NO_CULL_WALK,
                   _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_QUANT_NODES | _abi.RT_FLAG_CULL_WALK, _abi.RT_FLAG_LINEAR_SCAN):
         _compare(oracle, rq, sph, flags=flags)
+
+
+def test_tall_image_deep_paths_many_samples(ndev, oracle):
+    """A strip near the bottom of an image 70 000 rows tall (global rows beyond 16 bits); the 62-bounce limit on the default
+    engines of a 1 024-sphere scene (the path stack then does not fit beside an LDS-resident tree: the host must fall back);
+    500 samples per pixel (long per-pixel RNG streams and sums)."""
+    sph, _ = scenes.config("c3")
+    rq = _abi.default_request(width=5, height=70000, divisions=700, division_no=698, spp=2, max_bounces=3, seed=2)
+    _compare(oracle, rq, sph)
+    rq2 = _abi.default_request(width=48, height=30, divisions=1, spp=2, max_bounces=_abi.RT_MAX_BOUNCES, seed=4)
+    st = _compare(oracle, rq2, sph)
+    assert st.engine in (2, 4)
+    _compare(oracle, rq2, sph, flags=_abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_QUANT_NODES)
+    rq3 = _abi.default_request(width=12, height=8, divisions=1, spp=500, max_bounces=6, seed=6)
+    _compare(oracle, rq3, sph)
+    _compare(oracle, rq3, scenes.cornell16())
