@@ -140,3 +140,40 @@ def test_big_cases_covered_plain_and_culled_walks(ndev):
     if len(_BIG_ENGINES) < 6:
         pytest.skip("big cases did not run")
     assert 3 in _BIG_ENGINES and 5 in _BIG_ENGINES, _BIG_ENGINES
+
+
+N_MIXED = int(os.environ.get("RT_FUZZ_MIXED", "8"))
+
+
+@pytest.mark.parametrize("i", range(N_MIXED))
+def test_fuzz_big_mixed_scene(ndev, oracle, i):
+    """Thousands of spheres AND triangles in one scene: more spheres than triangles (the quantised walk validates triangle
+    leaves through their box chain) or more triangles (exact nodes, root tests compacted over mixed primitives)."""
+    g = np.random.default_rng(9000 + i)
+    ns, nt = [(5000, 3000), (2000, 6000), (9000, 500), (300, 4000)][i % 4]
+    sph = np.zeros(ns, _abi.SPHERE_DTYPE)
+    c = g.uniform([-30, -1, -70], [30, 12, -3], (ns, 3))
+    sph["cx"], sph["cy"], sph["cz"], sph["radius"] = c[:, 0], c[:, 1], c[:, 2], g.uniform(0.1, 0.6, ns)
+    sph["cx"][0], sph["cy"][0], sph["cz"][0], sph["radius"][0] = 0.0, -501.0, -20.0, 500.0
+    for ch in ("albedo_r", "albedo_g", "albedo_b"):
+        sph[ch] = g.uniform(0.1, 0.95, ns)
+    sph["roughness"] = g.choice([0.0, 0.0, 0.4, 1.0], ns)
+    sph["emission"] = np.where(g.uniform(size=ns) < 0.03, g.uniform(2, 6, ns), 0.0)
+    tri = np.zeros(nt, _abi.TRIANGLE_DTYPE)
+    a = g.uniform([-30, -1, -70], [30, 12, -3], (nt, 3))
+    tri["a"], tri["b"], tri["c"] = a, a + g.uniform(-1.2, 1.2, (nt, 3)), a + g.uniform(-1.2, 1.2, (nt, 3))
+    for ch in ("albedo_r", "albedo_g", "albedo_b"):
+        tri[ch] = g.uniform(0.1, 0.95, nt)
+    tri["roughness"] = g.choice([0.0, 0.3, 1.0], nt)
+    tri["emission"] = np.where(g.uniform(size=nt) < 0.02, 4.0, 0.0)
+    rq = _abi.default_request(width=192, height=108, divisions=1, spp=2, max_bounces=int(g.choice([3, 6])), seed=int(g.integers(0, 2**63)))
+    flags = [0, _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_QUANT_NODES, _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_EXACT_NODES][(i // 4) % 3]
+    ref, ref_f, info = oracle.render(rq, sph, tri, backend=1, want_f32=True)
+    r = rq.copy()
+    r.flags = flags
+    with rt.Scene(0, rt.World(sph, tri)) as sc:
+        rgb, f32, st = sc.render_tile(r, want_f32=True)
+    assert st.engine in (2, 3)
+    assert np.array_equal(rgb, ref), f"mixed case {i}: {int((rgb != ref).sum())} bytes differ (flags {flags}, engine {st.engine})"
+    assert np.array_equal(f32.view(np.uint32), ref_f.view(np.uint32)), f"mixed case {i}"
+    assert st.ray_segments == info["ray_segments"], f"mixed case {i}"
