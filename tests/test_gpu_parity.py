@@ -750,7 +750,8 @@ _EXTREME = {
     "zero_focus": dict(focus_distance=0.0), "negative_focal": dict(focal_length=-1.0), "t_min_zero": dict(t_min=0.0),
     "t_min_negative": dict(t_min=-5.0), "t_window_empty": dict(t_min=10.0, t_max=5.0), "t_max_tiny": dict(t_max=0.01),
     "seed_all_ones": dict(seed=0xFFFFFFFFFFFFFFFF), "seed_zero": dict(seed=0), "one_row_strips": dict(divisions=54, division_no=53),
-    "single_sample": dict(spp=1, max_bounces=1),
+    "single_sample": dict(spp=1, max_bounces=1), "zero_fov": dict(fov=0.0), "pi_fov": dict(fov=3.1415927), "negative_aperture": dict(aperture=-0.5),
+    "huge_focus": dict(focus_distance=1e30, aperture=0.3), "zero_focal": dict(focal_length=0.0),
 }
 
 
@@ -892,3 +893,26 @@ def test_tall_image_deep_paths_many_samples(ndev, oracle):
     rq3 = _abi.default_request(width=12, height=8, divisions=1, spp=500, max_bounces=6, seed=6)
     _compare(oracle, rq3, sph)
     _compare(oracle, rq3, scenes.cornell16())
+
+
+def test_subnormal_values(ndev, oracle):
+    """binary32 subnormals in the scene (radii, coordinates, albedo, emission) and therefore in intermediate results: the kernels
+    must not flush them (the reference's SSE arithmetic does not)."""
+    g = np.random.default_rng(61)
+    n = 120
+    sph = np.zeros(n, _abi.SPHERE_DTYPE)
+    sph["cx"], sph["cy"], sph["cz"] = g.uniform(-4, 4, n), g.uniform(-2, 3, n), g.uniform(-12, -2, n)
+    sph["radius"] = g.uniform(0.2, 0.9, n)
+    sph["cx"][:10] = g.uniform(-1, 1, 10) * 1e-40                # subnormal coordinates
+    sph["radius"][10:20] = 1e-41                                # subnormal radii
+    for c in ("albedo_r", "albedo_g", "albedo_b"):
+        sph[c] = g.uniform(0.2, 0.9, n)
+    sph["albedo_r"][20:50] = 3e-39                              # products with subnormal results
+    sph["albedo_g"][20:50] = 1e-20
+    sph["emission"][50:80] = 1e-40
+    sph["emission"][80:90] = 2e-38
+    sph["roughness"] = g.choice([0.0, 1.0, 1e-42], n)
+    rq = _abi.default_request(width=96, height=60, divisions=1, spp=4, max_bounces=6, seed=19)
+    for flags in (0, _abi.RT_FLAG_LINEAR_SCAN, _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_EXACT_NODES | _abi.RT_FLAG_NO_LDS_TREE,
+                  _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_QUANT_NODES):
+        _compare(oracle, rq, sph, flags=flags)
