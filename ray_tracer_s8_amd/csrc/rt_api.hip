@@ -282,18 +282,32 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     const bool want_stage = [] { const char* e = getenv("RT_NO_STAGE"); return !(e && atoi(e) != 0); }() &&
                             ((traverse && !ltree) || streamed);     // the kernels it is compiled into (see there)
     const bool list16 = traverse && !ltree && n_prims <= 65536u;          // 16-bit leaf-list entries: half the LDS
-    const size_t stage_bytes_wg = (size_t)rtk::STAGE_BYTES * ((ltree ? rtk::LTREE_BLOCK : rtk::BLOCK) / 64);
+    size_t stage_bytes_wg = (size_t)rtk::STAGE_BYTES * ((ltree ? rtk::LTREE_BLOCK : rtk::BLOCK) / 64);
+    uint32_t stage_slots = rtk::STAGE_SLOTS;
     const uint32_t stack_capped = sc->bvh_depth + 1;
     const uint32_t stack_need = sc->bvh_depth + (ltree ? 2u : 1u);
     uint32_t maxl = qnodes ? (uint32_t)rtk::MAXL : (uint32_t)rtk::MAXL_EXACT, stack_lds = stack_need;
     bool capped = false;
     if (traverse && qnodes) {
         const size_t per_wg = (160u * 1024u - 4096u) / 5u - 256u;     // 4 KiB of slack, 256 B static LDS
-        const size_t fixed = path_bytes + (size_t)stack_need * rtk::BLOCK * sizeof(uint32_t) + (want_stage ? stage_bytes_wg : 0);
         const size_t slot = (size_t)rtk::BLOCK * (list16 ? sizeof(uint16_t) : sizeof(uint32_t));
+        // the culled walk needs short leaf lists only (its candidates are few and tested early), so it trades list slots for
+        // staging slots: every tile that finds no free staging slot is stored byte by byte and written back many times over
+        // (c5 WRITE_SIZE: 3 slots 1.42 x the frame)
+        static const uint32_t cull_minl = [] { const char* e = getenv("RT_CULL_MINL"); return e ? (uint32_t)atoi(e) : 3u; }();
+        if (want_stage && cull) {
+            const size_t base = path_bytes + (size_t)stack_need * rtk::BLOCK * sizeof(uint32_t);
+            for (uint32_t s_ = rtk::STAGE_SLOTS_MAX; s_ > rtk::STAGE_SLOTS; s_--)
+                if (base + (size_t)s_ * rtk::STAGE_TILE_BYTES * (rtk::BLOCK / 64) + (size_t)cull_minl * slot <= per_wg) {
+                    stage_slots = s_;
+                    stage_bytes_wg = (size_t)s_ * rtk::STAGE_TILE_BYTES * (rtk::BLOCK / 64);
+                    break;
+                }
+        }
+        const size_t fixed = path_bytes + (size_t)stack_need * rtk::BLOCK * sizeof(uint32_t) + (want_stage ? stage_bytes_wg : 0);
         // (RT_FORCE_CAPPED / RT_STACK_LDS, read per launch: tests drive the capped-stack kernel with small trees)
         const bool force_capped = [] { const char* e = getenv("RT_FORCE_CAPPED"); return e && atoi(e) != 0; }();
-        if (!force_capped && fixed + (size_t)rtk::MINL * slot <= per_wg) {
+        if (!force_capped && fixed + (size_t)(stage_slots > rtk::STAGE_SLOTS ? cull_minl : (uint32_t)rtk::MINL) * slot <= per_wg) {
             maxl = (uint32_t)std::min<size_t>((size_t)rtk::MAXL, (per_wg - fixed) / slot);
         } else {
             const uint32_t cap = [] { const char* e = getenv("RT_STACK_LDS"); return e && atoi(e) > 0 ? (uint32_t)atoi(e) : STACK_LDS_MAX; }();
@@ -335,6 +349,7 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
         p.lds_cmp_off = (uint32_t)lds;
         lds += 1024u * (rtk::BLOCK / 64);
     }
+    p.stage_slots = stage_slots;
     p.lds_stage_off = 0xffffffffu;
     if (want_stage && lds + stage_bytes_wg <= LDS_LIMIT) {
         lds = (lds + 15) & ~(size_t)15;

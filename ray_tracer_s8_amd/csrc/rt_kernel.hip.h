@@ -54,6 +54,9 @@ constexpr int BLOCK = 256;       // 4 waves
 #ifndef RT_STEPS_PER_CHECK_X    // exact-node L2 kernel, straight-line step
 #define RT_STEPS_PER_CHECK_X 16
 #endif
+#ifndef RT_QUEUE_TAKE_MIN       // tiles a workgroup takes from the launch's queue per (memory-side) atomic, at least
+#define RT_QUEUE_TAKE_MIN 4
+#endif
 #ifndef RT_BF2                  // straight-line step in the uncapped quantised walks (see there)
 #define RT_BF2 1
 #endif
@@ -96,7 +99,7 @@ constexpr uint32_t LEAF_BIT = 0x80000000u;
 // Output staging (north_star: "coalesced HBM stores of the tile"): a wave collects the RGB8 bytes of up to STAGE_SLOTS of
 // its 64x1 tiles in LDS and writes a finished tile as 48 whole dwords = three whole 64-byte lines.  Byte stores of
 // single pixels reached HBM as partial lines: 1.3x (c3) to 13x (c5) write amplification (profiles/r01_*, r02_*).
-constexpr uint32_t STAGE_SLOTS = 3, STAGE_TILE_BYTES = 192, STAGE_BYTES = STAGE_SLOTS * STAGE_TILE_BYTES;
+constexpr uint32_t STAGE_SLOTS = 3, STAGE_SLOTS_MAX = 5, STAGE_TILE_BYTES = 192, STAGE_BYTES = STAGE_SLOTS * STAGE_TILE_BYTES;   // (the host may grant up to STAGE_SLOTS_MAX: KParams::stage_slots)
 constexpr uint32_t STAGE_DIRECT = 7;      // slot number of a pixel that is stored directly (no free slot, ragged tile)
 // (three slots spelt out below: as arrays the slot state left the scalar registers — 9 more VGPRs, one wave per SIMD
 // less for the quantised-node kernel)
@@ -123,6 +126,7 @@ struct KParams {
     uint32_t lds_rr_off;
     uint32_t lds_stack_off;      // traversal engine: per-lane stack, (bvh depth + 1) x 256 x u32
     uint32_t lds_cmp_off;        // compacted root tests (ISECT 2): 1 KiB per wave (offsets, distances, roots, hit flags); 0xffffffff: per-lane flush
+    uint32_t stage_slots;        // output staging: tiles a wave can hold in LDS (STAGE_SLOTS..STAGE_SLOTS_MAX)
     uint32_t lds_stage_off;      // output staging (STAGE_BYTES per wave); 0xffffffff: every pixel is stored directly
     uint32_t n_strips;           // strips in this launch
     uint32_t tiles_x, tiles_per_strip, n_tiles;   // tiles of 64 pixels: (1 << tile_wlog2) wide
@@ -653,9 +657,9 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 7 ? R
     // there into whole lines (c3: WRITE_SIZE 1.03 x the frame either way, profiles/r02_*), staging only cost registers.
     constexpr bool CAN_STAGE = (ISECT >= 1 && ISECT <= 4) || ISECT >= 7;
     const bool staging = CAN_STAGE && p.lds_stage_off != 0xffffffffu;
-    unsigned char* const stage_base = lds_raw + (staging ? p.lds_stage_off + (uint32_t)(tid >> 6) * STAGE_BYTES : 0u);
-    int s_left0 = -1, s_left1 = -1, s_left2 = -1;
-    uint8_t *s_dst0 = nullptr, *s_dst1 = nullptr, *s_dst2 = nullptr;
+    unsigned char* const stage_base = lds_raw + (staging ? p.lds_stage_off + (uint32_t)(tid >> 6) * (p.stage_slots * STAGE_TILE_BYTES) : 0u);
+    int s_left0 = -1, s_left1 = -1, s_left2 = -1, s_left3 = -1, s_left4 = -1;
+    uint8_t *s_dst0 = nullptr, *s_dst1 = nullptr, *s_dst2 = nullptr, *s_dst3 = nullptr, *s_dst4 = nullptr;
     uint32_t tile_slot = STAGE_DIRECT;        // slot of the wave's current tile
     uint32_t fin_slot = STAGE_DIRECT;         // per lane: slot of the pixel it finished in the last pass
 
@@ -666,11 +670,14 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 7 ? R
         if (staging && __ballot(fin_slot != STAGE_DIRECT)) {
             // ================= finished tiles: LDS -> three whole lines of the strip, by whatever lanes are left
             const unsigned long long m0 = __ballot(fin_slot == 0), m1 = __ballot(fin_slot == 1), m2 = __ballot(fin_slot == 2);
+            const unsigned long long m3 = __ballot(fin_slot == 3), m4 = __ballot(fin_slot == 4);
             fin_slot = STAGE_DIRECT;
             s_left0 -= (int)__builtin_popcountll(m0);
             s_left1 -= (int)__builtin_popcountll(m1);
             s_left2 -= (int)__builtin_popcountll(m2);
-            if (s_left0 == 0 || s_left1 == 0 || s_left2 == 0) {
+            s_left3 -= (int)__builtin_popcountll(m3);
+            s_left4 -= (int)__builtin_popcountll(m4);
+            if (s_left0 == 0 || s_left1 == 0 || s_left2 == 0 || s_left3 == 0 || s_left4 == 0) {
                 const unsigned long long act = __ballot(true);
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
                 const uint32_t nact = (uint32_t)__builtin_popcountll(act);
@@ -683,6 +690,8 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 7 ? R
                 if (s_left0 == 0) { put(0, s_dst0); s_left0 = -1; }
                 if (s_left1 == 0) { put(1, s_dst1); s_left1 = -1; }
                 if (s_left2 == 0) { put(2, s_dst2); s_left2 = -1; }
+                if (s_left3 == 0) { put(3, s_dst3); s_left3 = -1; }
+                if (s_left4 == 0) { put(4, s_dst4); s_left4 = -1; }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // reads done before the slot is written again
             }
         }
@@ -703,7 +712,7 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 7 ? R
                     unsigned long long live = __ballot(true);
                     uint32_t t = 0xffffffffu;
                     if (lane == (int)__builtin_ctzll(live)) {
-                        constexpr uint32_t WGC = (uint32_t)(BLOCK / 64);
+                        constexpr uint32_t WGC = (uint32_t)(BLOCK / 64) < (uint32_t)RT_QUEUE_TAKE_MIN ? (uint32_t)RT_QUEUE_TAKE_MIN : (uint32_t)(BLOCK / 64);
                         for (;;) {
                             const unsigned long long old = __hip_atomic_fetch_add(&wg_tiles, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             if ((uint32_t)old < (uint32_t)(old >> 32)) {
@@ -763,6 +772,8 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 7 ? R
                             if (s_left0 < 0) { tile_slot = 0; s_left0 = 64; s_dst0 = dst; }
                             else if (s_left1 < 0) { tile_slot = 1; s_left1 = 64; s_dst1 = dst; }
                             else if (s_left2 < 0) { tile_slot = 2; s_left2 = 64; s_dst2 = dst; }
+                            else if (p.stage_slots > 3u && s_left3 < 0) { tile_slot = 3; s_left3 = 64; s_dst3 = dst; }
+                            else if (p.stage_slots > 4u && s_left4 < 0) { tile_slot = 4; s_left4 = 64; s_dst4 = dst; }
                         }
                     }
                 }
