@@ -308,7 +308,8 @@ def main():
                      "per-lane traversal of the reference BVH (exact nodes gathered from L2)",
                      "per-lane traversal of the reference BVH (quantised nodes, exact leaf validation)",
                      "per-lane traversal of the reference BVH (exact nodes resident in LDS)",
-                     "per-lane traversal of the reference BVH (quantised nodes, nearer child first, distance culling, exact leaf validation)"]
+                     "per-lane traversal of the reference BVH (quantised nodes, nearer child first, distance culling, exact leaf validation)",
+                     "per-lane traversal of the reference BVH (exact nodes gathered from L2, nearer child first, distance culling)"]
         line = {
             "metric": "Mrays/sec @ 4K/8spp 1024-sphere" if args.workload == "c3" else f"Mrays/sec @ {args.workload}",
             "value": segs / elapsed / 1e6,
@@ -367,14 +368,14 @@ def main():
             },
             "roofline_linear": linear,
         }
-        if st.engine in (2, 3, 5):
+        if st.engine in (2, 3, 5, 6):
             # The L2-gather walks are bound by their node gathers, not by flops: beside the FP32 object, the
             # node records fetched per second against the chip's rate for fully divergent gathers of that record size,
             # measured by tools/ubench/gather_rate.hip (committed: profiles/r02_gather_rate.json).  Lanes that share a line
             # are cheaper than the microbenchmark's, so this fraction is an estimate and is not asserted <= 1.
             try:
                 gr = json.loads((ROOT / "profiles" / "r02_gather_rate.json").read_text())
-                key, nbytes, ngath = ("64B_4_gathers", 64, 4) if st.engine == 2 else ("32B_2_gathers", 32, 2)
+                key, nbytes, ngath = ("64B_4_gathers", 64, 4) if st.engine in (2, 6) else ("32B_2_gathers", 32, 2)
                 peak_rec = gr["lane_records_per_cycle_per_cu"][key]["64_lanes"] * gr["cus"] * gr["clock_mhz"] * 1e6
                 ach_rec = census["node_steps"] * scale / avg_launch_s
                 line["roofline_gather"] = {

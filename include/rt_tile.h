@@ -113,8 +113,8 @@ enum {
      * internal BVH nodes visited (rt_tile_stats.node_steps).  Same image; a few per cent slower, never the timed launch. */
     RT_FLAG_COUNT_STEPS = 1u << 9,
     /* Quantised walk, nearer child first, skipping every subtree whose box the ray enters beyond the running closest hit by
-     * more than a proven slack (scenes of spheres only; identical images).  Default for sphere scenes on the quantised
-     * nodes that are dense enough for it to pay (c5 and denser); these force it on / off (A/B runs, tests). */
+     * more than a proven slack (identical images).  Default for sphere scenes on the quantised nodes, and for scenes with
+     * triangles on the exact nodes, that are dense enough for it to pay (c5, terrains); these force it on / off (A/B runs, tests). */
     RT_FLAG_CULL_WALK = 1u << 10,
     RT_FLAG_NO_CULL_WALK = 1u << 11
 };
@@ -155,7 +155,8 @@ typedef struct rt_tile_stats {
                                    in LDS), 1 linear scan (scene streamed through LDS), 2 BVH traversal (exact nodes),
                                    3 BVH traversal (quantised nodes + exact leaf validation),
                                    4 BVH traversal, exact nodes resident in LDS,
-                                   5 BVH traversal, quantised nodes, nearer child first with distance culling */
+                                   5 BVH traversal, quantised nodes, nearer child first with distance culling,
+                                   6 BVH traversal, exact nodes, nearer child first with distance culling (scenes with triangles) */
     uint32_t broad_form;        /* linear engines: 0 = oc form, 1 = expanded form   */
     uint64_t node_steps;        /* traversal engines under RT_FLAG_COUNT_STEPS: internal BVH nodes visited
                                    (each = two child-box slab tests); 0 otherwise.  broad_candidates = leaves

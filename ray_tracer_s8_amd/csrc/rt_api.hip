@@ -114,6 +114,9 @@ struct rt_scene {
     float r_slack = 0.f;           //   largest radius among the other spheres
     bool cull_pays = false;        //   host heuristic: the scene is dense enough for the culled walk (build_host_scene)
     bool inverted_boxes = false;   // a sphere of negative radius: its AABB has lo > hi (sphere.rs:65-72), see launch_batch
+    float tri_k = 0.f, tri_diag = 0.f, tri_es = 0.f, tri_e = 0.f;   // culled walk over the exact nodes: maxima over the triangles not in `big`
+    bool xcull_pays = false;       //   host heuristic for scenes with triangles
+    bool tri_ok = false;
     float cull_density = 0.f;      //   the box density behind it
     rtbvh::QGrid grid;
     float leaf_density = 0.f;      // sum of primitive box areas / scene box area (node-format heuristic)
@@ -263,6 +266,12 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     const bool cull_want = cull_env >= 0 ? cull_env != 0
                            : (rq->flags & RT_FLAG_NO_CULL_WALK) ? false : ((rq->flags & RT_FLAG_CULL_WALK) != 0 || sc->cull_pays);
     const bool cull = qnodes && cull_want && sc->n_tri == 0 && std::isfinite(sc->r_slack);
+    // ... and over the exact nodes (kernel variant 7): scenes with triangles — the bound of cull_bound_tri — wherever the exact-node
+    // L2 walk is the engine; default where the host heuristic says it pays (xcull_pays), forced by the same flags
+    const bool xcull_want = cull_env >= 0 ? cull_env != 0
+                            : (rq->flags & RT_FLAG_NO_CULL_WALK) ? false : ((rq->flags & RT_FLAG_CULL_WALK) != 0 || sc->xcull_pays);
+    const bool xcull = traverse && !qnodes && !ltree && xcull_want && sc->n_tri > 0 && sc->tri_ok && std::isfinite(sc->r_slack) &&
+                       !sc->inverted_boxes;
     const bool streamed = !traverse && sc->n_sph_pad > RESIDENT_MAX;
     p.chunk = traverse ? 0 : (streamed ? STREAM_CHUNK : sc->n_sph_pad);
     p.n_chunks = p.chunk ? (sc->n_sph_pad + p.chunk - 1) / p.chunk : 0;
@@ -416,13 +425,17 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     p.big = sc->d_big;
     p.n_big = sc->n_big;
     p.r_slack = sc->r_slack;
-    const rtk::KernelFn kern = traverse ? rtk::kernel_traverse(ltree ? 3 : qnodes ? (cull_run ? (capped ? 6 : 5) : capped ? 2 : 1) : 0, count_steps) : rtk::kernel_linear(streamed, expanded);
+    p.tri_k = sc->tri_k;
+    p.tri_diag = sc->tri_diag;
+    p.tri_es = sc->tri_es;
+    p.tri_e = sc->tri_e;
+    const rtk::KernelFn kern = traverse ? rtk::kernel_traverse(ltree ? 3 : qnodes ? (cull_run ? (capped ? 6 : 5) : capped ? 2 : 1) : xcull ? 7 : 0, count_steps) : rtk::kernel_linear(streamed, expanded);
     HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, bs, lds));
     if (per_cu < 1) per_cu = 1;
     static const bool verbose = getenv("RT_VERBOSE") != nullptr;
     if (verbose)
         fprintf(stderr, "[rt] engine %d%s  lds %zu B  workgroups/CU %d  leaf slots %u  bvh depth %u  leaf density %.3f  prims %u\n",
-                traverse ? (ltree ? 4 : qnodes ? (cull_run ? 5 : 3) : 2) : (streamed ? 1 : 0), capped ? " (capped stack)" : "", lds, per_cu, maxl,
+                traverse ? (ltree ? 4 : qnodes ? (cull_run ? 5 : 3) : xcull ? 6 : 2) : (streamed ? 1 : 0), capped ? " (capped stack)" : "", lds, per_cu, maxl,
                 sc->bvh_depth, sc->leaf_density, n_prims);
     uint32_t blocks = (uint32_t)sc->ctx->n_cu * (uint32_t)per_cu;
     const uint32_t waves_per_wg = (uint32_t)bs / 64u;
@@ -454,7 +467,7 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     }
     HIPCHK(hipMemsetAsync(p.queue, 0, sizeof(unsigned long long), stream));
     HIPCHK(hipEventRecord(ev.a, stream));
-    sc->last_engine = traverse ? (ltree ? 4u : qnodes ? (cull_run ? 5u : 3u) : 2u) : (streamed ? 1u : 0u);
+    sc->last_engine = traverse ? (ltree ? 4u : qnodes ? (cull_run ? 5u : 3u) : xcull ? 6u : 2u) : (streamed ? 1u : 0u);
     sc->last_form = expanded ? 1u : 0u;
     hipLaunchKernelGGL(kern, grid, block, lds, stream, p);
     HIPCHK(hipGetLastError());
@@ -582,7 +595,7 @@ static int ensure_ctx(DeviceCtx* c) {
         for (int expanded = 0; expanded < 2; expanded++)
             HIPCHK(hipFuncSetAttribute((const void*)rtk::kernel_linear(streamed != 0, expanded != 0),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
-    for (int variant = 0; variant < 7; variant++)
+    for (int variant = 0; variant < 8; variant++)
         for (int stats = 0; stats < 2; stats++)
             HIPCHK(hipFuncSetAttribute((const void*)rtk::kernel_traverse(variant, stats != 0),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
@@ -626,6 +639,9 @@ struct HostScene {
     float r_slack = 0.f;             // ... the largest radius among the others
     bool cull_pays = false;          // enough of the rays hit something for nearer-first + culling to beat the plain walk
     bool inverted_boxes = false;     // some sphere has a negative radius
+    float tri_k = 0.f, tri_diag = 0.f, tri_es = 0.f, tri_e = 0.f;
+    bool xcull_pays = false;         // a scene with triangles that the culled walk over the exact nodes may take, and where it pays
+    bool tri_ok = false;             //   ... may take at all (every triangle has a finite bound or a place in the list)
     float cull_density = 0.f;        // sum of the other spheres' box areas / area of the box around them
 };
 
@@ -824,6 +840,67 @@ static void build_host_scene(const rt_sphere* sp, uint32_t ns, const rt_triangle
         const double root = ex * ey + ey * ez + ez * ex, diag = std::sqrt(ex * ex + ey * ey + ez * ez);
         hs.cull_density = root > 0.0 ? (float)(area / root) : 0.f;
         hs.cull_pays = nt == 0 && root > 0.0 && std::isfinite(area / root) && area / root >= 0.7 && (double)rs <= 0.05 * diag;
+        // Scenes with triangles (culled walk over the EXACT nodes, cull_bound_tri in rt_kernel.hip.h): its bound needs every
+        // triangle outside the `big` list to have K = |e1||e2| <= 0.25 (with the reference's |det| >= 1e-5 that keeps the
+        // computed determinant within 1.5 % of the true one) and carries the largest box diagonal as slack, so triangles with
+        // a larger K, or a box diagonal of more than 8 x the median, join the list (16 entries with the spheres; more: no culling).
+        if (nt > 0) {
+            std::vector<float> dg(nt), kk(nt), es(nt), em(nt);
+            for (uint32_t i = 0; i < nt; i++) {
+                double e1 = 0, e2 = 0, e3 = 0, d2 = 0;
+                for (int a3 = 0; a3 < 3; a3++) {
+                    const double ab = (double)tr[i].b[a3] - tr[i].a[a3], ac = (double)tr[i].c[a3] - tr[i].a[a3], bc = (double)tr[i].c[a3] - tr[i].b[a3];
+                    e1 += ab * ab; e2 += ac * ac; e3 += bc * bc;
+                    const double ext = (double)boxes[ns + i].hi[a3] - boxes[ns + i].lo[a3];
+                    d2 += ext * ext;
+                }
+                e1 = std::sqrt(e1); e2 = std::sqrt(e2); e3 = std::sqrt(e3);
+                dg[i] = (float)(std::sqrt(d2) * 1.0001);
+                kk[i] = (float)(e1 * e2 * 1.0001);
+                es[i] = (float)((e1 + e2) * 1.0001);
+                em[i] = (float)(std::max(e1, std::max(e2, e3)) * 1.0001);
+            }
+            std::vector<float> tmp(dg);
+            std::nth_element(tmp.begin(), tmp.begin() + nt / 2, tmp.end());
+            const float med_d = tmp[nt / 2];
+            std::vector<uint32_t> bigt;
+            bool ok = true;
+            for (uint32_t i = 0; i < nt && ok; i++) {
+                const bool fin = std::isfinite(dg[i]) && std::isfinite(kk[i]);
+                if (!fin) ok = false;
+                else if (kk[i] > 0.25f || dg[i] > 8.0f * med_d) bigt.push_back(ns + i);
+                if (bigt.size() + hs.n_big > 16) ok = false;
+            }
+            if (ok) {
+                std::vector<char> isb(nt, 0);
+                for (uint32_t q : bigt) isb[q - ns] = 1;
+                double tarea = 0.0;
+                for (uint32_t i = 0; i < nt; i++) {
+                    if (isb[i]) continue;
+                    hs.tri_k = fmaxf(hs.tri_k, kk[i]);
+                    hs.tri_diag = fmaxf(hs.tri_diag, dg[i]);
+                    hs.tri_es = fmaxf(hs.tri_es, es[i]);
+                    hs.tri_e = fmaxf(hs.tri_e, em[i]);
+                    const rtbvh::Box& b = boxes[ns + i];
+                    const double ex2 = (double)b.hi[0] - b.lo[0], ey2 = (double)b.hi[1] - b.lo[1], ez2 = (double)b.hi[2] - b.lo[2];
+                    tarea += ex2 * ey2 + ey2 * ez2 + ez2 * ex2;
+                    for (int a3 = 0; a3 < 3; a3++) {
+                        lo[a3] = fminf(lo[a3], b.lo[a3]);
+                        hi[a3] = fmaxf(hi[a3], b.hi[a3]);
+                    }
+                }
+                const double fx = (double)hi[0] - lo[0], fy = (double)hi[1] - lo[1], fz = (double)hi[2] - lo[2];
+                const double root2 = fx * fy + fy * fz + fz * fx, diag2 = std::sqrt(fx * fx + fy * fy + fz * fz);
+                const double dens = root2 > 0.0 ? (area + tarea) / root2 : 0.0;
+                if (hs.n_big) hs.big.resize(hs.n_big); else hs.big.clear();
+                for (uint32_t q : bigt) hs.big.push_back(q);
+                hs.n_big = (uint32_t)hs.big.size();
+                if (hs.big.empty()) hs.big.push_back(0);
+                hs.cull_density = (float)dens;
+                hs.xcull_pays = std::isfinite(dens) && dens >= 0.7 && (double)rs <= 0.05 * diag2 && (double)hs.tri_diag <= 0.05 * diag2;
+            }
+            hs.tri_ok = ok;
+        }
     }
 }
 
@@ -900,6 +977,12 @@ static int upload_scene(int device, const HostScene& hs, rt_scene** out) {
     sc->r_slack = hs.r_slack;
     sc->cull_pays = hs.cull_pays;
     sc->inverted_boxes = hs.inverted_boxes;
+    sc->tri_k = hs.tri_k;
+    sc->tri_diag = hs.tri_diag;
+    sc->tri_es = hs.tri_es;
+    sc->tri_e = hs.tri_e;
+    sc->xcull_pays = hs.xcull_pays;
+    sc->tri_ok = hs.tri_ok;
     sc->cull_density = hs.cull_density;
     SC_CHK(hipMalloc(&sc->d_counters, COUNTER_WORDS * sizeof(unsigned long long)));
     SC_CHK(hipMemsetAsync(sc->d_counters, 0, COUNTER_WORDS * sizeof(unsigned long long), ctx->stream));

@@ -157,6 +157,8 @@ struct KParams {
     const uint32_t* big;         // culled walk (ISECT 7): [n_big] spheres too large for the culling slack, root-tested at query start
     uint32_t n_big;
     float r_slack;               //   largest radius among the spheres NOT in big[]
+    float tri_k, tri_diag, tri_es, tri_e;   // culled walk over the exact nodes (ISECT 9), triangles NOT in big[]: largest |e1||e2|, largest box
+                                 //   diagonal, largest |e1| + |e2|, largest edge (cull_bound_tri); all 0 without triangles
     uint32_t refill_eighths;     // traversal: finished lanes are refilled once <= this many eighths of the live lanes still walk
     uint32_t n_internal;         // internal nodes of the tree (= TravNode count)
     uint32_t lds_node_off;       // LDS-resident tree (ISECT 5): byte offsets of the staged nodes ...
@@ -341,6 +343,14 @@ __device__ __forceinline__ bool intersects_aabb_finite(V3 o, const RayAux& a, fl
                                           __builtin_fmaxf(z0, z1));
     return __builtin_fmaxf(ray_min, 0.0f) <= ray_max;
 }
+// intersects_aabb_finite with the slab entry and exit returned (the culled walk over the exact nodes orders and skips by them)
+__device__ __forceinline__ void slabs_finite(V3 o, const RayAux& a, float4 lo, float4 hi, float& ray_min, float& ray_max) {
+    const float x0 = (lo.x - o.x) * a.inv.x, x1 = (hi.x - o.x) * a.inv.x;
+    const float y0 = (lo.y - o.y) * a.inv.y, y1 = (hi.y - o.y) * a.inv.y;
+    const float z0 = (lo.z - o.z) * a.inv.z, z1 = (hi.z - o.z) * a.inv.z;
+    ray_min = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0, x1), __builtin_fminf(y0, y1)), __builtin_fminf(z0, z1));
+    ray_max = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0, x1), __builtin_fmaxf(y0, y1)), __builtin_fmaxf(z0, z1));
+}
 // Would BVH::traverse (bvh_impl.rs:373-398) have returned this primitive?  Every node on the
 // leaf's path to the root must pass the AABB test its parent stores for it.
 //
@@ -499,20 +509,37 @@ __device__ __forceinline__ float cull_bound(float best, V3 o, float r_slack) {
     return (best + a) * (1.0f + 0x1p-8f) + 0x1p-19f * (q * q);
 }
 
+// The same for TRIANGLES (mesh.rs:109-161, Moller-Trumbore in f32; u = 2^-24).  With e1, e2 the rounded edges, K = |e1||e2| and
+// |det| >= 1e-5 (the reference's own rejection threshold), the computed determinant is the true one up to a factor
+// 1 +- 0.0602 K, so for K <= 0.25 the returned root x and the computed barycentrics are those of the true ray-plane
+// intersection t*, u*, v* up to |t* - x| <= K (0.134 x + 0.072 Es) and a point at most D = K (0.138 x + 0.199 Es) + 3 u E outside the
+// triangle (Es = |e1| + |e2|, E the longest edge; |o - A| <= 1.07 (x + Es) was used).  A point that close to the triangle is
+// that close to its AABB, and a ray that enters the AABB at T_X > t* has travelled at most the diameter of the AABB inflated
+// by D between the two: t* >= T_X - diag_X - 3.47 D.  Together: x (1 + 0.613 K) >= T_X - diag_X - 0.763 K Es - 11 u E.  The bound
+// below carries twice these K terms, the same (1 + 2^-8) and |o|_1 terms as cull_bound for the float evaluation of the box
+// entries and of the compared distance, and the maxima over the triangles that are not in the scene's `big` list
+// (K > 0.25 or a box far larger than the rest: tested at every query start instead).
+__device__ __forceinline__ float cull_bound_tri(float best, V3 o, float k, float diag, float es, float e) {
+    const float o1 = __builtin_fabsf(o.x) + __builtin_fabsf(o.y) + __builtin_fabsf(o.z);
+    return (best + 0x1p-21f * o1) * (1.0f + 1.25f * k) * (1.0f + 0x1p-8f) + diag + 1.6f * k * es + 0x1p-18f * o1 + 1e-6f * e;
+}
+
 // ------------------------------------------------------------------ the kernel
 // ISECT selects the closest-hit engine: 0 = linear scan, scene resident in LDS; 1 = linear scan, scene streamed
 // through LDS in chunks; 2 = per-lane traversal of the reference BVH (exact 64-byte nodes); 3 = the same walk over
 // 32-byte nodes whose boxes are rounded outwards onto a 16-bit grid, every reached leaf being validated with the
 // reference's exact own-leaf AABB test.
 template <int ISECT, bool EXPANDED, int BS = BLOCK, bool STATS = false>
-__global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 7 ? RT_MINWAVES_CULL : ISECT >= 3 ? RT_MINWAVES_QTRAV : ISECT == 2 ? RT_MINWAVES_TRAV : RT_MINWAVES) void rt_tile_kernel(const KParams p) {
+__global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? RT_MINWAVES_TRAV : ISECT >= 7 ? RT_MINWAVES_CULL : ISECT >= 3 ? RT_MINWAVES_QTRAV : ISECT == 2 ? RT_MINWAVES_TRAV : RT_MINWAVES) void rt_tile_kernel(const KParams p) {
     constexpr int BLOCK = BS;                        // threads per workgroup = stride of the per-lane LDS arrays
     constexpr bool STREAMED = (ISECT == 1);
     constexpr bool TRAVERSE = (ISECT >= 2);
     constexpr bool QNODES = (ISECT == 3 || ISECT == 4 || ISECT == 7 || ISECT == 8);   // traversal over 32-byte conservatively quantised nodes
     // ISECT 7: ... nearer child first, and a subtree whose box the ray enters beyond the running closest hit (plus a proven
     // slack, cull_bound) is not entered.  Spheres only.  Candidates then arrive out of depth-first order: ties by rank.
-    constexpr bool CULL = (ISECT == 7 || ISECT == 8);      // (8: with the capped LDS stack)
+    constexpr bool CULL = (ISECT == 7 || ISECT == 8 || ISECT == 9);      // (8: with the capped LDS stack; 9: over the EXACT nodes,
+                                                                         //  where triangles may take part — cull_bound_tri)
+    constexpr bool XNODES = (ISECT == 2 || ISECT == 9);    // exact 64-byte nodes gathered from L2
     constexpr bool CAPPED = (ISECT == 4 || ISECT == 8);            // ... whose stack keeps p.stack_lds entries in LDS, deeper ones in HBM
     // ISECT 5: the exact-node walk with the WHOLE tree (and the materials) resident in LDS, one 1024-thread workgroup
     // per CU; references, stack and leaf lists are 16-bit
@@ -624,6 +651,13 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 7 ? R
     // registers across the walk (the culled kernel spilled seven registers without this, which showed as 2.5 x the
     // fetch traffic past L2).
     auto AUX = [&]() -> RayAux { return QNODES ? ray_aux(d, (p.flags & 8u) != 0) : aux; };
+    // culled walks: nothing entered beyond this distance can beat or tie the hit at distance `best` (spheres: cull_bound;
+    // the exact-node variant also holds triangles: cull_bound_tri; a scene of both takes the larger)
+    auto far_bound = [&](float best) -> float {
+        float b = cull_bound(best, o, p.r_slack);
+        if (ISECT == 9 && p.n_tri) b = __builtin_fmaxf(b, cull_bound_tri(best, o, p.tri_k, p.tri_diag, p.tri_es, p.tri_e));
+        return b;
+    };
     V3 td = mk(0, 0, 0);                     // linear engines: 2 * d of the current segment
     bool in_trav = false;
     uint32_t t_ref = 0, t_sp = 0, t_cnt = 0;
@@ -886,12 +920,18 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 7 ? R
                 t_far = __builtin_inff();
                 for (uint32_t j = 0; j < p.n_big; j++) {
                     const uint32_t prim = p.big[j];
-                    const float4 g = at32(p.geom, prim);
                     float t;
-                    if (exact_sphere(o, 2.0f * d, mk(g.x, g.y, g.z), g.w, p.t_min, p.t_max, t))
+                    bool hit;
+                    if (prim < p.n_sph) {
+                        const float4 g = at32(p.geom, prim);
+                        hit = exact_sphere(o, 2.0f * d, mk(g.x, g.y, g.z), g.w, p.t_min, p.t_max, t);
+                    } else {
+                        hit = exact_triangle(o, d, p.tri + 9 * (size_t)(prim - p.n_sph), p.t_min, p.t_max, t);
+                    }
+                    if (hit)
                         consider_if<true>(h, (int)prim, o, d, t, [&]() { return bvh_reaches(p.bvh_nodes, p.leaf_of[prim], o, AUX()); }, p.leaf_of);
                 }
-                if (h.idx >= 0) t_far = cull_bound(h.dist, o, p.r_slack);
+                if (h.idx >= 0) t_far = far_bound(h.dist);
             }
             if (TRAVERSE) {
                 t_ref = p.root_ref;
@@ -930,6 +970,8 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 7 ? R
                                     return intersects_aabb_finite(o, AUX(), make_float4(s.x - s.w, s.y - s.w, s.z - s.w, 0.f),
                                                                   make_float4(s.x + s.w, s.y + s.w, s.z + s.w, 0.f));
                                 }, p.leaf_of);
+                            else if (CULL)
+                                consider<1>(h, (int)prim, o, d, t, aux, p.bvh_nodes, p.leaf_of);       // (out of depth-first order: ties by rank)
                             else
                                 consider<0>(h, (int)prim, o, d, t, aux, p.bvh_nodes, p.leaf_of);
                         }
@@ -938,13 +980,15 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 7 ? R
                             if (QNODES)
                                 consider_if(h, (int)prim, o, d, t,
                                             [&]() { return !qfin || bvh_reaches(p.bvh_nodes, p.leaf_of[prim], o, AUX()); });
+                            else if (CULL)
+                                consider<1>(h, (int)prim, o, d, t, aux, p.bvh_nodes, p.leaf_of);
                             else
                                 consider<0>(h, (int)prim, o, d, t, aux, p.bvh_nodes, p.leaf_of);
                         }
                     }
                 }
                 t_cnt = 0;
-                if (CULL && h.idx >= 0) t_far = cull_bound(h.dist, o, p.r_slack);
+                if (CULL && h.idx >= 0) t_far = far_bound(h.dist);
             };
             // ---- Compacted root tests (exact-node L2 kernel).  The per-lane flush above runs as many rounds as the longest
             // list of the wave, each at a handful of lanes (mesh workload: 17 rounds of 5.7 lanes per loop round, half of the
@@ -952,7 +996,7 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 7 ? R
             // pair j is tested by lane j mod 64 — full rounds of 64 — with the owner's ray fetched across lanes; the owner then
             // takes the first minimum of its own pairs in list order, exactly as `consider<0>` does.  Wave-uniform call: every
             // lane still in the loop takes part as a worker, `want` marks the lanes whose lists are flushed.
-            constexpr bool COMPACT = (ISECT == 2);
+            constexpr bool COMPACT = XNODES;
             auto flush_c = [&](bool want) {
                 const uint32_t cnt = want ? t_cnt : 0u;
                 // exclusive prefix sum and total of the (at most 4-bit) counts from ballots: no cross-lane traffic
@@ -975,6 +1019,9 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 7 ? R
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 int best_k = -1;                                     // owner: slot of the winner among this flush's pairs
                 float best_t = 0.f;
+                auto own_prim = [&](uint32_t k) -> uint32_t {
+                    return p.list16 ? (uint32_t)lc16[k * BLOCK + tid16] : lc32[k * BLOCK + tid];
+                };
                 for (uint32_t base = 0; base < total; base += n_act) {
                     const uint32_t j = base + rank;
                     const bool valid = j < total;
@@ -1023,7 +1070,13 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 7 ? R
                         for (uint32_t k = k0; k < k1; k++) {
                             if (!w_hit[k - base]) continue;
                             const float dk = w_dist[k - base];
-                            if (best_k < 0 ? (h.idx < 0 || h.dist > dk) : (h.dist > dk)) {
+                            bool take = best_k < 0 ? (h.idx < 0 || h.dist > dk) : (h.dist > dk);
+                            if (CULL && !take && h.dist == dk && (best_k >= 0 || h.idx >= 0)) {
+                                // culled walk: candidates arrive out of depth-first order, an equal distance goes to the earlier leaf
+                                const uint32_t cur = best_k >= 0 ? own_prim((uint32_t)best_k) : (uint32_t)h.idx;
+                                take = p.leaf_of[own_prim(k - excl)] < p.leaf_of[cur];
+                            }
+                            if (take) {
                                 h.dist = dk;
                                 best_k = (int)(k - excl);
                                 best_t = w_root[k - base];
@@ -1033,10 +1086,11 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 7 ? R
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // reads done before the next round's writes
                 }
                 if (best_k >= 0) {
-                    h.idx = (int)(p.list16 ? (uint32_t)lc16[(uint32_t)best_k * BLOCK + tid16] : lc32[(uint32_t)best_k * BLOCK + tid]);
+                    h.idx = (int)own_prim((uint32_t)best_k);
                     h.t = best_t;
                 }
                 if (want) t_cnt = 0;
+                if (CULL && want && h.idx >= 0) t_far = far_bound(h.dist);
             };
             // Per-lane stack.  The exact-node kernel keeps all of it in LDS ((depth + 1) KiB per workgroup); the quantised
             // kernel (large scenes, deep trees) keeps p.stack_lds entries there and the rare deeper ones in HBM, so
@@ -1155,7 +1209,7 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 7 ? R
                 // unrolled step code: one copy instead of RT_STEPS_PER_CHECK; c3 +1 %, 45 % less code)
                 // (CULL: a lane without a hit yet tests its leaves now, so that the walk can start skipping)
                 if (COMPACT && p.lds_cmp_off != 0xffffffffu) {
-                    const bool want = in_trav && t_cnt == ML;
+                    const bool want = in_trav && (t_cnt == ML || (CULL && t_cnt >= (uint32_t)RT_CULL_FLUSH_MIN && h.idx < 0));
                     if (__ballot(want)) flush_c(want);
                 } else
                 if (in_trav && (t_cnt == ML || (CULL && t_cnt >= (uint32_t)RT_CULL_FLUSH_MIN && h.idx < 0))) flush();
@@ -1167,7 +1221,7 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 7 ? R
                 // hot line) and fails both tests, so it appends and pops; a full list stalls the lane until the flush between
                 // blocks; the right child is stored to the free stack slot pushed or not.  Taken when every walking lane of the
                 // wave carries its ray in grid units; a wave with a fallback lane runs the step below.
-                constexpr bool BF2 = (RT_BF2 != 0) && (ISECT == 2 || QNODES);
+                constexpr bool BF2 = (RT_BF2 != 0) && (XNODES || QNODES);
                 if (BF2 && !__ballot(in_trav && !(QNODES ? qfin : aux.finite))) {
 #pragma unroll
                     for (int rep = 0; rep < (QNODES ? RT_STEPS_PER_CHECK_Q : RT_STEPS_PER_CHECK_X); rep++)
@@ -1197,8 +1251,20 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT >= 7 ? R
                         } else {
                         const float4* __restrict__ nd = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.trav) + ((is_leaf ? 0u : t_ref) << 6));
                         const float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
-                        hl = intersects_aabb_finite(o, aux, n0, n1);
-                        hr = intersects_aabb_finite(o, aux, n2, n3);
+                        if (CULL) {
+                            // the crate's test for a finite inverse direction (intersects_aabb_finite), with the entry distances kept:
+                            // a box entered beyond t_far is skipped, the nearer child goes first
+                            float lmin, lmax, rmin_, rmax_;
+                            slabs_finite(o, aux, n0, n1, lmin, lmax);
+                            slabs_finite(o, aux, n2, n3, rmin_, rmax_);
+                            le = __builtin_fmaxf(lmin, 0.0f);
+                            re = __builtin_fmaxf(rmin_, 0.0f);
+                            hl = le <= lmax && le <= t_far;
+                            hr = re <= rmax_ && re <= t_far;
+                        } else {
+                            hl = intersects_aabb_finite(o, aux, n0, n1);
+                            hr = intersects_aabb_finite(o, aux, n2, n3);
+                        }
                         c0 = __float_as_uint(n0.w);
                         c1 = __float_as_uint(n1.w);
                         }
@@ -1625,6 +1691,7 @@ KernelFn kernel_linear(bool streamed, bool expanded);
 KernelFn kernel_traverse(int variant, bool stats = false);   // 0: exact nodes, 1: quantised nodes, 2: quantised nodes with the capped LDS stack,
                                          // 3: exact nodes, whole tree resident in LDS (1024-thread workgroups)
                                          // 5: quantised nodes, nearer child first, distance culling (spheres only); 6: the same, capped LDS stack
+                                         // 7: exact nodes, nearer child first, distance culling (spheres and triangles)
                                          // stats: the variant that also counts node visits (RT_FLAG_COUNT_STEPS)
 constexpr int LTREE_BLOCK = 1024;
 

@@ -10,6 +10,7 @@ KernelFn kernel_traverse(int variant, bool stats) {
         if (variant == 3) return rt_tile_kernel<5, false, LTREE_BLOCK, true>;
         if (variant == 5) return rt_tile_kernel<7, false, BLOCK, true>;
         if (variant == 6) return rt_tile_kernel<8, false, BLOCK, true>;
+        if (variant == 7) return rt_tile_kernel<9, false, BLOCK, true>;
         return variant == 2   ? rt_tile_kernel<4, false, BLOCK, true>
                : variant == 1 ? rt_tile_kernel<3, false, BLOCK, true>
                               : rt_tile_kernel<2, false, BLOCK, true>;
@@ -17,6 +18,7 @@ KernelFn kernel_traverse(int variant, bool stats) {
     if (variant == 3) return rt_tile_kernel<5, false, LTREE_BLOCK>;
     if (variant == 5) return rt_tile_kernel<7, false>;
     if (variant == 6) return rt_tile_kernel<8, false>;
+    if (variant == 7) return rt_tile_kernel<9, false>;
     return variant == 2 ? rt_tile_kernel<4, false> : variant == 1 ? rt_tile_kernel<3, false> : rt_tile_kernel<2, false>;
 }
 }  // namespace rtk

@@ -168,7 +168,7 @@ def test_checksum_of_strip_checksums_is_reproducible(ndev):
     assert digests[0] == digests[1]
 
 
-@pytest.mark.parametrize("flags", [0, 64, 64 | 256, 128])
+@pytest.mark.parametrize("flags", [0, 64, 64 | 256, 128, 2048, 64 | 2048])
 def test_mesh_of_100k_triangles(ndev, oracle, flags):
     """The only primitive the shipped controller emits (controller obj.rs:27), at the scale SURVEY 8f-2 names: a generated
     100 352-triangle OBJ through the controller's ingest rules (obj.build_world), every traversal engine against the oracle."""
@@ -188,4 +188,5 @@ def test_mesh_of_100k_triangles(ndev, oracle, flags):
     ref, _, info = oracle.render(one, None, tri, backend=1)
     assert np.array_equal(np.concatenate(outs), ref)
     assert st.ray_segments == info["ray_segments"]
-    assert st.engine == (3 if flags & 128 else 2)           # meshes keep the exact nodes unless the quantised walk is forced
+    # meshes keep the exact nodes unless the quantised walk is forced; this terrain is dense enough for the culled walk over them
+    assert st.engine == (3 if flags & 128 else 6 if not (flags & _abi.RT_FLAG_NO_CULL_WALK) else 2)

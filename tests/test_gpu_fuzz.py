@@ -20,7 +20,10 @@ ENGINE_FLAGS = [0, _abi.RT_FLAG_LINEAR_SCAN, _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT
                 # the culled walk (nearer child first, distance culling) forced onto small scenes (sphere-only ones take it)
                 _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_QUANT_NODES | _abi.RT_FLAG_CULL_WALK,
                 _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_QUANT_NODES | _abi.RT_FLAG_CULL_WALK | _abi.RT_FLAG_FULL_CHAIN,
-                _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_QUANT_NODES | _abi.RT_FLAG_NO_CULL_WALK]
+                _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_QUANT_NODES | _abi.RT_FLAG_NO_CULL_WALK,
+                # the culled walk over the exact nodes (scenes with triangles take it)
+                _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_EXACT_NODES | _abi.RT_FLAG_NO_LDS_TREE | _abi.RT_FLAG_CULL_WALK,
+                _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_EXACT_NODES | _abi.RT_FLAG_NO_LDS_TREE | _abi.RT_FLAG_CULL_WALK | _abi.RT_FLAG_FULL_CHAIN]
 
 
 @pytest.fixture(scope="module")
@@ -167,13 +170,14 @@ def test_fuzz_big_mixed_scene(ndev, oracle, i):
     tri["roughness"] = g.choice([0.0, 0.3, 1.0], nt)
     tri["emission"] = np.where(g.uniform(size=nt) < 0.02, 4.0, 0.0)
     rq = _abi.default_request(width=192, height=108, divisions=1, spp=2, max_bounces=int(g.choice([3, 6])), seed=int(g.integers(0, 2**63)))
-    flags = [0, _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_QUANT_NODES, _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_EXACT_NODES][(i // 4) % 3]
+    flags = [0, _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_QUANT_NODES, _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_EXACT_NODES | _abi.RT_FLAG_NO_CULL_WALK,
+             _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_EXACT_NODES | _abi.RT_FLAG_CULL_WALK][(i // 4) % 4]
     ref, ref_f, info = oracle.render(rq, sph, tri, backend=1, want_f32=True)
     r = rq.copy()
     r.flags = flags
     with rt.Scene(0, rt.World(sph, tri)) as sc:
         rgb, f32, st = sc.render_tile(r, want_f32=True)
-    assert st.engine in (2, 3)
+    assert st.engine in (2, 3, 6)
     assert np.array_equal(rgb, ref), f"mixed case {i}: {int((rgb != ref).sum())} bytes differ (flags {flags}, engine {st.engine})"
     assert np.array_equal(f32.view(np.uint32), ref_f.view(np.uint32)), f"mixed case {i}"
     assert st.ray_segments == info["ray_segments"], f"mixed case {i}"

@@ -916,3 +916,39 @@ def test_subnormal_values(ndev, oracle):
     for flags in (0, _abi.RT_FLAG_LINEAR_SCAN, _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_EXACT_NODES | _abi.RT_FLAG_NO_LDS_TREE,
                   _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_QUANT_NODES):
         _compare(oracle, rq, sph, flags=flags)
+
+
+def test_grazing_rays_over_triangle_floors(ndev, oracle):
+    """The regime the triangle bound of the culled walk has to survive: rays almost parallel to layers of small floor triangles a
+    hair below the camera, so that the reference's determinant is a few times its 1e-5 threshold and its roots are off by
+    per cent; edges of 0.49 put |e1||e2| next to the bound's limit of 0.25.  Culled and plain walks over the exact nodes, the
+    quantised walk, the linear engine."""
+    g = np.random.default_rng(7)
+    tris = []
+    for layer, y in enumerate((-1e-3, -2.5e-3, -6e-3, -2e-2)):
+        alb = [(0.9, 0.2, 0.2), (0.2, 0.9, 0.2), (0.2, 0.2, 0.9), (0.8, 0.8, 0.2)][layer]
+        for ix in range(-8, 8):
+            for iz in range(2, 60):
+                if g.uniform() < 0.35:
+                    continue                                              # holes: the layers below show through
+                e = 0.49                                                  # |e1||e2| = 0.24: just inside the bound's K <= 0.25
+                x0, z0 = e * ix, -e * iz
+                jy = y * (1.0 + 0.2 * g.uniform())
+                tris.append(((x0, jy, z0), (x0 + e, jy, z0), (x0, jy, z0 - e), *alb, float(g.choice([0.0, 1.0])), 0.0))
+                tris.append(((x0 + e, jy, z0 - e), (x0, jy, z0 - e), (x0 + e, jy, z0), *alb, 0.0, 0.0))
+    tr = np.array(tris, dtype=_abi.TRIANGLE_DTYPE)
+    sph = np.zeros(30, _abi.SPHERE_DTYPE)
+    sph["cx"], sph["cy"], sph["cz"] = g.uniform(-3, 3, 30), g.uniform(0.0, 0.6, 30), g.uniform(-28, -3, 30)
+    sph["radius"] = g.uniform(0.1, 0.4, 30)
+    sph["albedo_r"] = sph["albedo_g"] = sph["albedo_b"] = 0.7
+    sph["roughness"] = g.choice([0.0, 1.0], 30)
+    # a narrow vertical field of view around the horizon: every pixel row is a grazing angle of 1e-5 ... 1e-2
+    rq = _abi.default_request(width=96, height=81, divisions=1, spp=3, max_bounces=4, seed=29, aperture=0.0, fov=0.02, t_max=200.0)
+    engines = []
+    for flags in (_abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_EXACT_NODES | _abi.RT_FLAG_NO_LDS_TREE | _abi.RT_FLAG_CULL_WALK,
+                  _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_EXACT_NODES | _abi.RT_FLAG_NO_LDS_TREE | _abi.RT_FLAG_NO_CULL_WALK,
+                  0, _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_QUANT_NODES, _abi.RT_FLAG_LINEAR_SCAN):
+        st = _compare(oracle, rq, sph, tr, flags=flags)
+        engines.append(st.engine)
+    assert engines[0] == 6 and engines[1] == 2
+    assert st.ray_segments > rq.width * rq.height * rq.spp            # the floors are hit
