@@ -36,6 +36,8 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 PEAK_FP32_VALU_TFLOPS = 157.3      # MI355X_MICROARCH.md: peak FP32 vector (FMA = 2 flop)
+PEAK_FP32_NOFMA_TFLOPS = 78.65     # the same pipe issuing add / sub / mul (1 flop per lane per issue): SURVEY 8(d)'s peak for
+                                   # the parity build (-ffp-contract=off: the slab and root tests are sub / mul, not fma)
 PEAK_HBM_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FLOPS_PER_TEST = 20                # faithful ray-sphere test = 20 flop + 1 sqrt
 FLOPS_PER_NODE_STEP = 48           # two child-box slab tests: 2 x (6 sub + 6 mul + 12 min / max / compare)
@@ -57,8 +59,13 @@ def parse_args():
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-buffer (PCIe-inclusive) pass: profiling runs "
                     "then see whole-frame launches only")
     ap.add_argument("--no-linear", action="store_true", help="skip the linear-engine launches behind roofline_linear")
+    ap.add_argument("--no-others", action="store_true", help="skip the other_workloads passes (c2 / c4 / c5 / mesh, 3 steps each)")
+    ap.add_argument("--no-frame", action="store_true", help="skip the frame_path pass (wall-clock of the frame context)")
     ap.add_argument("--strong", action="store_true", help="strong scaling, the controller's split (BASELINE c4 / c5): ONE "
                     "frame, strip d goes to rank d mod N; value = the frame's ray segments / max-rank time")
+    ap.add_argument("--frame", action="store_true", help="print ONLY the frame_path object: wall-clock frames of --workload "
+                    "through a persistent rt_frame_ctx (host buffer out), --steps frames after the first")
+    ap.add_argument("--frame-queue", action="store_true", help="with --frame: the strip-queue assignment (RT_FLAG_FRAME_QUEUE)")
     ap.add_argument("--cpu-scale", type=int, default=1, help="CPU baseline renders the frame at 1/scale resolution")
     ap.add_argument("--flags", type=int, default=0, help="rt_tile_request.flags (1 = exact scan)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -107,6 +114,76 @@ def cpu_baseline(workload: str, scale: int):
     }
 
 
+def frame_path(rt, _abi, scenes, workload: str, dev_index: int, frames: int = 3, queue: bool = False):
+    """Wall clock of the in-process product path that replaces the controller's dispatch + assembly (controller
+    main.rs:47-75, 109-115): rt_frame_ctx_render into a host frame buffer — kernels, strip downloads, dispatcher
+    wake-ups, everything — frame after frame of one job.  Frame 1 carries the one-off costs (page-locking the buffer,
+    the world's host preparation + upload); the later frames must not."""
+    import numpy as np
+    sph, tri, rq = scenes.config_world(workload)
+    if queue:
+        rq.flags |= _abi.RT_FLAG_FRAME_QUEUE
+    buf = np.zeros(rq.width * rq.height * 3, np.uint8)            # (zeros: the pages exist before the first frame)
+    t0 = time.perf_counter()
+    fc = rt.FrameContext(devices=[dev_index])
+    t1 = time.perf_counter()
+    fc.set_world(rt.World(sph, tri))
+    t2 = time.perf_counter()
+    recs = []
+    for i in range(1 + max(frames, 1)):
+        ta = time.perf_counter()
+        _, fs = fc.render(rq, out=buf)
+        tb = time.perf_counter()
+        recs.append({"wall_ms_python": (tb - ta) * 1e3, "wall_ms": fs.wall_ms, "pin_ms": fs.pin_ms, "scene_ms": fs.scene_ms,
+                     "kernel_ms": fs.kernel_ms, "d2h_exposed_ms": fs.d2h_exposed_ms, "host_ms": fs.host_ms,
+                     "pinned": int(fs.pinned), "launches": int(fs.totals.n_launches),
+                     "segments": int(fs.totals.ray_segments)})
+    fc.close()
+    steady = sorted(recs[1:], key=lambda r: r["wall_ms_python"])[len(recs[1:]) // 2]      # median later frame
+    out = {"workload": workload, "n_devices": 1, "assignment": "strip queue" if queue else "static: strip k -> device k mod n",
+           "ctx_create_ms": (t1 - t0) * 1e3, "set_world_ms": (t2 - t1) * 1e3,
+           "first_frame": recs[0], "steady_frame": steady, "frames_after_first": len(recs) - 1,
+           "mrays_per_s": steady["segments"] / (steady["wall_ms_python"] / 1e3) / 1e6,
+           "note": "wall clock around rt_frame_ctx_render (host RGB8 frame out); the first frame page-locks the buffer "
+                   "(pin_ms) and is charged the world's preparation + upload (scene_ms); later frames of the job pay neither"}
+    return out
+
+
+def other_workload(rt, scenes, workload: str, dev_index: int, stream: int, torch, steps: int = 3):
+    """One more BASELINE config through the same device-resident entry point, `steps` timed launches after one
+    warm-up, own scene: value / engine / ms, so that every number the README quotes is in the driver's line."""
+    sph, tri, rq0 = scenes.config_world(workload)
+    strip_bytes = (rq0.height // rq0.divisions) * rq0.width * 3
+    out = torch.empty(rq0.divisions * strip_bytes, dtype=torch.uint8, device="cuda")
+    reqs = []
+    for d in range(rq0.divisions):
+        r = rq0.copy()
+        r.division_no = d
+        reqs.append(r)
+    ptrs = [out.data_ptr() + i * strip_bytes for i in range(len(reqs))]
+    with rt.Scene(dev_index, rt.World(sph, tri)) as sc:
+        sc.render_tiles_device(reqs, ptrs, strip_bytes, stream)
+        torch.cuda.synchronize()
+        sc.collect()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            sc.render_tiles_device(reqs, ptrs, strip_bytes, stream)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        st = sc.collect()
+    del out
+    return {"value": float(st.ray_segments) / (t1 - t0) / 1e6, "unit": "Mrays/s", "ms_per_frame": (t1 - t0) / steps * 1e3,
+            "kernel_ms_per_launch": st.kernel_ms / max(st.n_launches, 1), "launches": int(st.n_launches), "steps": steps,
+            "engine": int(st.engine), "spheres": len(sph), "triangles": len(tri),
+            "frame": f"{rq0.width}x{rq0.height}, {rq0.spp} spp, depth {rq0.max_bounces}, {rq0.divisions} strips in one launch"}
+
+
+def _build_flags_ok() -> bool:
+    """False if librt_s8.so was compiled with RT_EXTRA_HIPCC_FLAGS (an experiment's variant): such a line is not the product's."""
+    from ray_tracer_s8_amd import build
+    return build.built_with_default_flags()
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -141,6 +218,11 @@ def main():
 
     n_dev = rt.init()
     assert dev_index < n_dev
+    if args.frame:
+        if world != 1:
+            raise SystemExit("--frame is the in-process path: run it with --gpus 1")
+        print(json.dumps({"frame_path": frame_path(rt, _abi, scenes, args.workload, dev_index, args.steps, args.frame_queue)}), flush=True)
+        return
     sph, tri, rq0 = scenes.config_world(args.workload)
     rq0.flags = args.flags
     if args.strong:
@@ -269,6 +351,63 @@ def main():
                           "every sphere against every segment"}
         assert 0.0 < linear["frac"] <= 1.0, linear
 
+    # ---- the other BASELINE configs and the mesh workload, 3 launches each after the timed region (rank 0, N = 1)
+    others = None
+    if rank == 0 and world == 1 and not args.no_others and args.workload == "c3" and not args.flags and not args.overlap:
+        others = {}
+        for w in ("c2", "c4", "c5", "mesh"):
+            try:
+                others[w] = other_workload(rt, scenes, w, dev_index, stream, torch)
+            except Exception as e:                   # a failure here must not take the headline line with it
+                others[w] = {"error": repr(e)}
+    # ---- the in-process frame path (rt_frame_ctx: host frame out, dispatcher threads, pinned buffer), wall clock
+    fpath = None
+    if rank == 0 and world == 1 and not args.no_frame and args.workload == "c3" and not args.flags and not args.overlap:
+        fpath = {}
+        for w in ("c3", "c4"):
+            try:
+                fpath[w] = frame_path(rt, _abi, scenes, w, dev_index, 3)
+            except Exception as e:
+                fpath[w] = {"error": repr(e)}
+    # ---- N > 1: BASELINE config 4 as the controller splits it — ONE c4 frame, strip d -> rank d mod N, max-rank time —
+    # beside the weak-scaling value of the line, so that a scaling run records it at every N
+    strong_c4 = None
+    if world > 1 and not args.strong and args.workload == "c3" and not args.no_others:
+        s4, t4, r4 = scenes.config_world("c4")
+        if r4.divisions % world == 0:
+            mine = strips_for_worker(r4.divisions, rank, world)
+            sb4 = (r4.height // r4.divisions) * r4.width * 3
+            out4 = torch.empty(len(mine) * sb4, dtype=torch.uint8, device="cuda")
+            rq4 = []
+            for d_ in mine:
+                r_ = r4.copy()
+                r_.division_no = d_
+                rq4.append(r_)
+            p4 = [out4.data_ptr() + i * sb4 for i in range(len(rq4))]
+            with rt.Scene(dev_index, rt.World(s4, t4)) as sc4:
+                sc4.render_tiles_device(rq4, p4, sb4, stream)
+                torch.cuda.synchronize()
+                sc4.collect()
+                barrier()
+                torch.cuda.synchronize()
+                ta = time.perf_counter()
+                for _ in range(3):
+                    sc4.render_tiles_device(rq4, p4, sb4, stream)
+                torch.cuda.synchronize()
+                barrier()
+                tb = time.perf_counter()
+                st4 = sc4.collect()
+            tt = torch.tensor([tb - ta], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            cc = torch.tensor([float(st4.ray_segments)], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(cc, op=dist.ReduceOp.SUM)
+            strong_c4 = {"value": float(cc.item()) / float(tt.item()) / 1e6, "unit": "Mrays/s", "scaling": "strong",
+                         "ms_per_frame": float(tt.item()) / 3 * 1e3, "steps": 3, "n_gpus": world,
+                         "strips_per_rank": len(mine),
+                         "workload": f"c4: ONE {r4.width}x{r4.height} / {r4.spp} spp frame, {r4.divisions} strips, strip d -> rank d mod {world} "
+                                     "(controller main.rs:47-75), max-rank time"}
+            del out4
+
     if rank == 0:
         n_sph = len(sph)
         launches = max(st.n_launches, 1)
@@ -290,6 +429,9 @@ def main():
             work = {"tests_per_segment": n_sph, "flops_per_test": FLOPS_PER_TEST,
                     "source": "SURVEY 8(d): the linear engine tests every sphere against every segment"}
         achieved_tflops = flops_per_launch / avg_launch_s / 1e12
+        # the slab and root tests are sub / mul / compare — no fma under -ffp-contract=off — so the pipe's rate for them is
+        # one flop per lane per issue: SURVEY 8(d)'s non-FMA peak.  (The linear engines' broad phase IS fma: full peak.)
+        peak_tflops = PEAK_FP32_NOFMA_TFLOPS if st.engine >= 2 else PEAK_FP32_VALU_TFLOPS
         hbm_bytes_per_launch = strip_bytes * len(reqs) / max(len(batches), 1) + 36 * n_sph + 56 * len(tri)   # RGB8 out + scene in
 
         def committed(name):
@@ -302,8 +444,8 @@ def main():
                 d = dict(d)
                 d["source"] = f"committed profile profiles/{name} (rocprofv3 --pmc pass of this command, not measured in this run)"
             return d
-        traffic_rec = committed("r02_hbm_traffic.json")
-        issue = committed("r02_valu_issue.json")
+        traffic_rec = committed("r03_hbm_traffic.json") or committed("r02_hbm_traffic.json")
+        issue = committed("r03_valu_issue.json") or committed("r02_valu_issue.json")
         eng_names = ["linear scan, scene resident in LDS", "linear scan, scene streamed through LDS",
                      "per-lane traversal of the reference BVH (exact nodes gathered from L2)",
                      "per-lane traversal of the reference BVH (quantised nodes, exact leaf validation)",
@@ -333,6 +475,7 @@ def main():
                 "segments_per_primary": segs / prim,
                 "engine": eng_names[st.engine],
                 "flags": args.flags,
+                "default_build_flags": _build_flags_ok(),
                 "overlapped_steps": bool(args.overlap),
                 "pcie_inclusive": pcie,
                 "broad_candidates_per_segment": float(st.broad_candidates) / max(float(st.ray_segments), 1.0),
@@ -341,9 +484,15 @@ def main():
             "roofline": {
                 "bound": "valu",
                 "achieved": achieved_tflops,
-                "peak": PEAK_FP32_VALU_TFLOPS,
+                "peak": peak_tflops,
                 "unit": "TFLOP/s",
-                "frac": achieved_tflops / PEAK_FP32_VALU_TFLOPS,
+                "frac": achieved_tflops / peak_tflops,
+                "peak_note": "non-FMA FP32 vector peak (sub / mul / compare, 1 flop per lane per issue; SURVEY 8(d) parity mode)"
+                             if st.engine >= 2 else "FP32 vector peak, FMA = 2 flop (the broad phase is packed fma)",
+                # SURVEY 8(d)'s own figure, as named there: ray_segments x 20 x N / t / 78.6e12.  For the traversal engines
+                # it exceeds 1 — they do O(log N) tests per segment, not N — so it is NOT a fraction of the hardware; it
+                # says how many times faster than a perfect linear scan at that peak the launch was.
+                "valu_fraction_8d": algorithmic_equiv_tflops / PEAK_FP32_NOFMA_TFLOPS,
                 "traffic": traffic_rec.get("bytes_per_launch") if isinstance(traffic_rec, dict) else None,
                 "traffic_source": traffic_rec.get("source") if isinstance(traffic_rec, dict) else None,
                 "kernel": "rtk::rt_tile_kernel (" + eng_names[st.engine] + ")",
@@ -367,6 +516,9 @@ def main():
                 },
             },
             "roofline_linear": linear,
+            "other_workloads": others,
+            "frame_path": fpath,
+            "strong_c4": strong_c4,
         }
         if st.engine in (2, 3, 5, 6):
             # The L2-gather walks are bound by their node gathers, not by flops: beside the FP32 object, the

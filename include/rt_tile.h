@@ -35,7 +35,10 @@ extern "C" {
 #define RT_API __attribute__((visibility("default")))
 #endif
 
-#define RT_ABI_VERSION 2u      /* 2: rt_tile_stats.node_steps appended */
+#define RT_ABI_VERSION 3u      /* 2: rt_tile_stats.node_steps appended
+                                  3: `world_index` (the position of every primitive in RenderInfo.world) on the entry
+                                     points that take a world; the persistent frame context rt_frame_ctx_*;
+                                     RT_FLAG_FRAME_QUEUE / RT_FLAG_FRAME_NO_PIN replace two environment variables */
 
 /* ---- status codes --------------------------------------------------------------- */
 typedef enum rt_status {
@@ -116,7 +119,13 @@ enum {
      * more than a proven slack (identical images).  Default for sphere scenes on the quantised nodes, and for scenes with
      * triangles on the exact nodes, that are dense enough for it to pay (c5, terrains); these force it on / off (A/B runs, tests). */
     RT_FLAG_CULL_WALK = 1u << 10,
-    RT_FLAG_NO_CULL_WALK = 1u << 11
+    RT_FLAG_NO_CULL_WALK = 1u << 11,
+    /* Frame-level flags (rt_render_frame / rt_frame_ctx_render only; the tile entry points ignore them).
+     * FRAME_QUEUE: the devices pull strips one at a time, bottom of the frame (the expensive strips) first, from a shared
+     * host-atomic queue, two launches in flight per device, instead of the static split strip k -> devices[k % n].
+     * FRAME_NO_PIN: do not page-lock the caller's frame buffer (downloads then go through the runtime's staging). */
+    RT_FLAG_FRAME_QUEUE = 1u << 12,
+    RT_FLAG_FRAME_NO_PIN = 1u << 13
 };
 
 typedef struct rt_tile_request {
@@ -182,6 +191,16 @@ RT_API void rt_tile_request_defaults(rt_tile_request* req);
 /* Bytes of one strip = (H / div) * W * 3  (main.rs:53-59).  0 on bad args. */
 RT_API size_t rt_tile_bytes(const rt_tile_request* req);
 
+/* ---- the world's order ------------------------------------------------------------ */
+/* RenderInfo.world is ONE list, `Vec<Object>`, whose entries are spheres or triangles in any order
+ * (ray-tracer-slave/src/lib.rs:11, shapes/mod.rs:23-27), and that order is observable: BVH::build numbers the shapes by
+ * their position in it (bvh_impl.rs:421-427), so the halves of its `split_at(len / 2)` fallback (:277-291), the order of
+ * the leaves BVH::traverse returns, and with it the winner among hits at exactly equal distance (`min_by` keeps the first,
+ * shapes/mod.rs:177-182) all follow it.  The ABI carries the world as two typed arrays; `world_index` restores the order:
+ * world_index[i] (i < n_spheres) is the position of spheres[i] in RenderInfo.world, world_index[n_spheres + j] that of
+ * triangles[j]; it must be a permutation of 0 .. n_spheres + n_triangles - 1 (else RT_ERR_BAD_ARG).  NULL means the
+ * spheres in their order followed by the triangles in theirs.  Copied during the call; the caller keeps ownership. */
+
 /* ---- one strip, host buffers: replaces slave main.rs:53-83 ---------------------- */
 
 /* Render strip `req->division_no` of the frame on `device` into out_rgb
@@ -194,6 +213,7 @@ RT_API size_t rt_tile_bytes(const rt_tile_request* req);
 RT_API int rt_render_tile(int device, const rt_tile_request* req,
                           const rt_sphere* spheres, uint32_t n_spheres,
                           const rt_triangle* triangles, uint32_t n_triangles,
+                          const uint32_t* world_index,
                           uint8_t* out_rgb, size_t out_len,
                           float* out_f32, rt_tile_stats* stats);
 
@@ -205,6 +225,7 @@ typedef struct rt_scene rt_scene;
 RT_API int rt_scene_create(int device,
                            const rt_sphere* spheres, uint32_t n_spheres,
                            const rt_triangle* triangles, uint32_t n_triangles,
+                           const uint32_t* world_index,
                            rt_scene** out_scene);
 RT_API void rt_scene_destroy(rt_scene* scene);
 
@@ -242,19 +263,64 @@ RT_API int rt_scene_render_tiles(rt_scene* scene, const rt_tile_request* reqs, u
 RT_API int rt_scene_collect(rt_scene* scene, rt_tile_stats* stats);
 
 /* ---- whole frame: replaces controller dispatch + assembly ----------------------- */
-/* (controller main.rs:47-75 `for division_no in 0..divisions` and :109-115 stitch).
- * The world's host-side preparation (device layouts, the candidate-filter BVH) is done once and
- * uploaded to every device; one host thread per device renders its strips and the RGB8 strips
- * are stitched by division_no into out_rgb (H*W*3), which is page-locked for the duration of
- * the call so that the downloads run as DMA under the kernels.  Strip assignment: strip k goes
- * to devices[k % n_devices], all strips of a device in one launch (default); with the
- * environment variable RT_FRAME_QUEUE=1 the devices instead pull strips one at a time, bottom
- * of the frame (the expensive strips) first, from a shared host-atomic queue, two launches in
- * flight per device.  Same bytes either way.  devices==NULL means all devices.
- * req->division_no is ignored.  height % divisions must be 0. */
+/* (controller main.rs:47-75 `for division_no in 0..divisions` and :109-115 stitch.)
+ *
+ * rt_frame_ctx is the controller's state for a JOB: a set of devices, each with one dispatcher thread, the job's world
+ * resident in its HBM, its streams and its strip buffers, plus the page-locked registration of the caller's frame buffer.
+ * Everything is created once — the context by rt_frame_ctx_create, the world by rt_frame_ctx_set_world, the registration
+ * by the first rt_frame_ctx_render that sees a buffer — and reused: a second frame of the job (same world, same buffer)
+ * registers, allocates, uploads and spawns nothing.  rt_render_frame is the one-shot wrapper (create, set world, render
+ * one frame, destroy).
+ *
+ * Strip assignment: strip k goes to devices[k % n_devices], all strips of a device in one launch, the downloads of all but
+ * the last quarter of them under the last launch (default); with RT_FLAG_FRAME_QUEUE in req->flags the devices pull strips
+ * one at a time, bottom of the frame first, two launches in flight per device.  The RGB8 strips are stitched by
+ * division_no into out_rgb (H*W*3).  Same bytes either way.  No collective, no peer traffic: strips are independent.
+ * req->division_no is ignored.  height % divisions must be 0 (the controller's from_vec(..).unwrap() panics otherwise). */
+
+typedef struct rt_frame_ctx rt_frame_ctx;
+
+/* Where the wall time of one rt_frame_ctx_render call went (milliseconds).  Devices run concurrently: kernel_ms and
+ * d2h_exposed_ms are those of the device that finished last. */
+typedef struct rt_frame_stats {
+    rt_tile_stats totals;       /* counters summed over the devices; kernel_ms / d2h_ms = the largest per-device value */
+    float wall_ms;              /* the whole call, steady clock                                                        */
+    float pin_ms;               /* page-locking out_rgb in this call (0 when the buffer was already registered)       */
+    float scene_ms;             /* host-side world preparation + uploads charged to this frame: the duration of the
+                                   rt_frame_ctx_set_world since the previous frame (0 for every later frame of the job) */
+    float kernel_ms;            /* HIP-event time of the launches of the device that finished last                    */
+    float d2h_exposed_ms;       /* last launch done -> last strip byte on the host, same device                       */
+    float host_ms;              /* wall_ms - pin_ms - kernel_ms - d2h_exposed_ms: dispatch, thread wake-up, joins      */
+    uint32_t n_devices;
+    uint32_t pinned;            /* 1: out_rgb is page-locked (strip downloads are direct DMA)                          */
+} rt_frame_stats;
+
+/* devices == NULL (or n_devices <= 0) means all devices.  A device may be listed more than once (several dispatcher
+ * threads sharing it).  Starts one dispatcher thread per entry. */
+RT_API int rt_frame_ctx_create(const int* devices, int n_devices, rt_frame_ctx** out_ctx);
+/* Make this world the job's: host-side preparation once (device layouts, the candidate-filter BVH), one upload per
+ * device.  Replaces the previous world of the context.  Must not race with rt_frame_ctx_render on the same context. */
+RT_API int rt_frame_ctx_set_world(rt_frame_ctx* ctx,
+                                  const rt_sphere* spheres, uint32_t n_spheres,
+                                  const rt_triangle* triangles, uint32_t n_triangles,
+                                  const uint32_t* world_index);
+/* Render one frame of the job into out_rgb (>= H*W*3 bytes).  The context page-locks out_rgb (hipHostRegister) the
+ * first time it sees it and keeps the registration until another buffer is passed or the context is destroyed — pass the
+ * same buffer for every frame of a job and only the first pays pin_ms.  The caller must not free a buffer the context
+ * still holds: call rt_frame_ctx_release_buffer (or destroy the context) first.  Synchronous; one call at a time per
+ * context.  stats may be NULL. */
+RT_API int rt_frame_ctx_render(rt_frame_ctx* ctx, const rt_tile_request* req,
+                               uint8_t* out_rgb, size_t out_len, rt_frame_stats* stats);
+/* Drop the page-locked registration of the last frame buffer (no-op if none). */
+RT_API int rt_frame_ctx_release_buffer(rt_frame_ctx* ctx);
+/* Stops the dispatcher threads, releases the worlds, buffers, streams and the registration. */
+RT_API void rt_frame_ctx_destroy(rt_frame_ctx* ctx);
+
+/* One-shot: a context over `devices`, this world, one frame, everything released again. */
 RT_API int rt_render_frame(const int* devices, int n_devices, const rt_tile_request* req,
                            const rt_sphere* spheres, uint32_t n_spheres,
                            const rt_triangle* triangles, uint32_t n_triangles,
+                           const uint32_t* world_index,
                            uint8_t* out_rgb, size_t out_len, rt_tile_stats* stats);
 
 #ifdef __cplusplus

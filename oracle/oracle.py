@@ -54,9 +54,10 @@ def hardware_threads() -> int:
     return load().rt_oracle_hardware_threads()
 
 
-def render(req, spheres, triangles=None, backend: int = 0, nthreads: int = 0, want_f32: bool = False):
+def render(req, spheres, triangles=None, backend: int = 0, nthreads: int = 0, want_f32: bool = False, world_index=None):
     """Render one strip.  `req` is any ctypes struct with rt_tile_request layout.
-    Returns (rgb uint8 [Hs*W*3], f32 or None, info dict)."""
+    world_index: position of every sphere, then of every triangle, in the reference's `world: Vec<Object>` (None: spheres
+    then triangles).  Returns (rgb uint8 [Hs*W*3], f32 or None, info dict)."""
     lib = load()
     sph = np.ascontiguousarray(spheres) if spheres is not None else np.zeros(0, np.uint8)
     tri = np.ascontiguousarray(triangles) if triangles is not None else np.zeros(0, np.uint8)
@@ -68,9 +69,12 @@ def render(req, spheres, triangles=None, backend: int = 0, nthreads: int = 0, wa
     segs = C.c_uint64(0)
     ms = C.c_double(0)
     bms = C.c_double(0)
+    wi = None if world_index is None else np.ascontiguousarray(world_index, dtype=np.uint32)
+    if wi is not None and wi.size != ns + nt:
+        raise ValueError("world_index: one entry per primitive")
     rc = lib.rt_oracle_render(C.byref(req), _p(sph), C.c_uint32(ns), _p(tri), C.c_uint32(nt), C.c_int(backend),
                               C.c_int(nthreads), _p(out), _p(outf) if want_f32 else None, C.byref(segs),
-                              C.byref(ms), C.byref(bms))
+                              C.byref(ms), C.byref(bms), _p(wi) if wi is not None else None)
     if rc != 0:
         raise ValueError(f"rt_oracle_render: bad arguments ({rc})")
     return out, outf, {"ray_segments": segs.value, "render_ms": ms.value, "bvh_build_ms": bms.value}

@@ -444,6 +444,9 @@ inline void color_as_slice(Color c, uint8_t* p) {  // S/color.rs:13-19
 struct Scene {
     std::vector<rt_sphere> spheres;
     std::vector<rt_triangle> tris;
+    // `world: Vec<Object>` (S/lib.rs:11) as the ABI carries it: two typed arrays plus, for every position of the list, the
+    // object that stands there (objects are numbered spheres first, then triangles).  Identity when no world_index came.
+    std::vector<uint32_t> order;
     float t_min, t_max;
     BVH bvh;
     bool use_bvh;
@@ -530,7 +533,9 @@ bool intersect(const Scene& sc, const Ray& ray, const std::vector<uint32_t>* can
     float best_d = 0.f;
     size_t n = cands ? cands->size() : sc.count();
     for (size_t k = 0; k < n; k++) {
-        uint32_t idx = cands ? (*cands)[k] : (uint32_t)k;
+        // both lists hold POSITIONS in `world` (BVH::build numbers the shapes by position, bvh_impl.rs:421-427; the
+        // linear back-end walks the list front to back)
+        uint32_t idx = sc.order[cands ? (*cands)[k] : (uint32_t)k];
         V3 p;
         if (!object_hit_point(sc, idx, ray, &p)) continue;
         float d = length(p - ray.origin);
@@ -696,10 +701,12 @@ void render_span(const Job& job, uint32_t yl, uint32_t x_begin, uint32_t x_end, 
 }
 
 Scene make_scene(const rt_tile_request* rq, const rt_sphere* sp, uint32_t ns, const rt_triangle* tr, uint32_t nt,
-                 int backend) {
+                 int backend, const uint32_t* world_index = nullptr) {
     Scene sc;
     sc.spheres.assign(sp, sp + ns);
     sc.tris.assign(tr, tr + nt);
+    sc.order.resize((size_t)ns + nt);
+    for (uint32_t i = 0; i < ns + nt; i++) sc.order[world_index ? world_index[i] : i] = i;   // (a permutation: checked by the caller)
     sc.t_min = rq->t_min;
     sc.t_max = rq->t_max;
     sc.use_bvh = backend == 1;
@@ -708,8 +715,8 @@ Scene make_scene(const rt_tile_request* rq, const rt_sphere* sp, uint32_t ns, co
 void build_scene_bvh(Scene& sc) {
     std::vector<AABB> boxes;
     boxes.reserve(sc.count());
-    for (auto& s : sc.spheres) boxes.push_back(sphere_aabb(s));
-    for (auto& t : sc.tris) boxes.push_back(triangle_aabb(t));
+    for (uint32_t obj : sc.order)               // shapes in `world` order (S/main.rs:60: BVH::build(&mut req.world))
+        boxes.push_back(obj < sc.spheres.size() ? sphere_aabb(sc.spheres[obj]) : triangle_aabb(sc.tris[obj - sc.spheres.size()]));
     sc.bvh = bvh_build(boxes);
 }
 Camera make_camera(const rt_tile_request* rq) {  // S/main.rs:42-50
@@ -728,16 +735,25 @@ extern "C" {
 // Rows are distributed dynamically over threads (rayon-like); results do not depend on
 // nthreads because every pixel owns its RNG stream.
 // out_f32 may be NULL.  *bvh_build_ms (may be NULL) receives the BVH build time.
+// world_index (may be NULL): include/rt_tile.h "the world's order".
 __attribute__((visibility("default"))) int rt_oracle_render(const rt_tile_request* rq, const rt_sphere* sp,
                                                             uint32_t ns, const rt_triangle* tr, uint32_t nt,
                                                             int backend, int nthreads, uint8_t* out_rgb,
                                                             float* out_f32, uint64_t* ray_segments,
-                                                            double* render_ms, double* bvh_build_ms) {
+                                                            double* render_ms, double* bvh_build_ms,
+                                                            const uint32_t* world_index) {
     if (!rq || !out_rgb || rq->width == 0 || rq->height == 0 || rq->divisions == 0 ||
         rq->division_no >= rq->divisions || rq->spp == 0)
         return -1;
+    if (world_index) {
+        std::vector<char> seen((size_t)ns + nt, 0);
+        for (uint32_t i = 0; i < ns + nt; i++) {
+            if (world_index[i] >= ns + nt || seen[world_index[i]]) return -2;
+            seen[world_index[i]] = 1;
+        }
+    }
     Job job;
-    job.sc = make_scene(rq, sp, ns, tr, nt, backend);
+    job.sc = make_scene(rq, sp, ns, tr, nt, backend, world_index);
     auto t0 = std::chrono::steady_clock::now();
     if (job.sc.use_bvh) build_scene_bvh(job.sc);
     auto t1 = std::chrono::steady_clock::now();

@@ -5,11 +5,11 @@ mirror of the reference's RenderInfo/ImageSlice surface.  Nothing here imports o
 """
 from ._abi import (RT_FLAG_EXACT_SCAN, RT_FLAG_NO_BVH_CULL, RT_FLAG_NONE, SPHERE_DTYPE, TRIANGLE_DTYPE, RtError, TileRequest,
                    TileStats, default_request)
-from .interface import (Controller, ImageSlice, RenderInfo, RenderMeta, RenderSettings, Scene, Slave, World, init,
+from .interface import (Controller, FrameContext, ImageSlice, RenderInfo, RenderMeta, RenderSettings, Scene, Slave, World, init,
                         render_frame_native)
 
 __all__ = [
     "RT_FLAG_EXACT_SCAN", "RT_FLAG_NO_BVH_CULL", "RT_FLAG_NONE", "SPHERE_DTYPE", "TRIANGLE_DTYPE", "RtError", "TileRequest", "TileStats",
-    "default_request", "Controller", "ImageSlice", "RenderInfo", "RenderMeta", "RenderSettings", "Scene", "Slave",
+    "default_request", "Controller", "FrameContext", "ImageSlice", "RenderInfo", "RenderMeta", "RenderSettings", "Scene", "Slave",
     "World", "init", "render_frame_native",
 ]

@@ -10,7 +10,7 @@ import numpy as np
 
 from . import build as _build
 
-RT_ABI_VERSION = 2          # include/rt_tile.h RT_ABI_VERSION; load() refuses a library of another version
+RT_ABI_VERSION = 3          # include/rt_tile.h RT_ABI_VERSION; load() refuses a library of another version
 
 # ---- status codes (rt_status)
 RT_OK = 0
@@ -37,6 +37,8 @@ RT_FLAG_NO_LDS_TREE = 256
 RT_FLAG_COUNT_STEPS = 512
 RT_FLAG_CULL_WALK = 1024
 RT_FLAG_NO_CULL_WALK = 2048
+RT_FLAG_FRAME_QUEUE = 4096          # frame-level (rt_render_frame / rt_frame_ctx_render): dynamic strip queue
+RT_FLAG_FRAME_NO_PIN = 8192         # frame-level: do not page-lock the caller's frame buffer
 RT_MAX_BOUNCES = 62
 
 # numpy dtypes with the exact layout of rt_sphere / rt_triangle (no padding)
@@ -79,8 +81,18 @@ class TileStats(C.Structure):
     ]
 
 
+class FrameStats(C.Structure):
+    """rt_frame_stats: where the wall time of one rt_frame_ctx_render call went (ms)."""
+    _fields_ = [
+        ("totals", TileStats), ("wall_ms", C.c_float), ("pin_ms", C.c_float), ("scene_ms", C.c_float),
+        ("kernel_ms", C.c_float), ("d2h_exposed_ms", C.c_float), ("host_ms", C.c_float),
+        ("n_devices", C.c_uint32), ("pinned", C.c_uint32),
+    ]
+
+
 assert C.sizeof(TileRequest) == 64
 assert C.sizeof(TileStats) == 64
+assert C.sizeof(FrameStats) == 96
 
 
 def default_request(**kw) -> TileRequest:
@@ -140,10 +152,10 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     lib.rt_tile_request_defaults.restype = None
     lib.rt_tile_bytes.argtypes = [C.POINTER(TileRequest)]
     lib.rt_tile_bytes.restype = C.c_size_t
-    lib.rt_render_tile.argtypes = [C.c_int, C.POINTER(TileRequest), vp, C.c_uint32, vp, C.c_uint32,
+    lib.rt_render_tile.argtypes = [C.c_int, C.POINTER(TileRequest), vp, C.c_uint32, vp, C.c_uint32, vp,
                                    vp, C.c_size_t, vp, C.POINTER(TileStats)]
     lib.rt_render_tile.restype = C.c_int
-    lib.rt_scene_create.argtypes = [C.c_int, vp, C.c_uint32, vp, C.c_uint32, C.POINTER(vp)]
+    lib.rt_scene_create.argtypes = [C.c_int, vp, C.c_uint32, vp, C.c_uint32, vp, C.POINTER(vp)]
     lib.rt_scene_create.restype = C.c_int
     lib.rt_scene_destroy.argtypes = [vp]
     lib.rt_scene_destroy.restype = None
@@ -160,8 +172,21 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     lib.rt_scene_collect.argtypes = [vp, C.POINTER(TileStats)]
     lib.rt_scene_collect.restype = C.c_int
     lib.rt_render_frame.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(TileRequest), vp, C.c_uint32,
-                                    vp, C.c_uint32, vp, C.c_size_t, C.POINTER(TileStats)]
+                                    vp, C.c_uint32, vp, vp, C.c_size_t, C.POINTER(TileStats)]
     lib.rt_render_frame.restype = C.c_int
+    lib.rt_frame_ctx_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
+    lib.rt_frame_ctx_create.restype = C.c_int
+    lib.rt_frame_ctx_set_world.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, vp]
+    lib.rt_frame_ctx_set_world.restype = C.c_int
+    lib.rt_frame_ctx_render.argtypes = [vp, C.POINTER(TileRequest), vp, C.c_size_t, C.POINTER(FrameStats)]
+    lib.rt_frame_ctx_render.restype = C.c_int
+    lib.rt_frame_ctx_release_buffer.argtypes = [vp]
+    lib.rt_frame_ctx_release_buffer.restype = C.c_int
+    lib.rt_frame_ctx_destroy.argtypes = [vp]
+    lib.rt_frame_ctx_destroy.restype = None
+    # test / tool hook, not part of rt_tile.h: one knob of the launch path by its environment-variable name
+    lib.rt_debug_set.argtypes = [C.c_char_p, C.c_int]
+    lib.rt_debug_set.restype = C.c_int
     _lib = lib
     return lib
 
@@ -182,5 +207,24 @@ def as_triangles(a) -> np.ndarray:
     return a
 
 
-def ptr(a: np.ndarray):
-    return a.ctypes.data_as(C.c_void_p) if a.size else None
+def ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None and a.size else None
+
+
+def as_world_index(a, n: int):
+    """world_index argument: None, or one uint32 position per primitive (spheres, then triangles)."""
+    if a is None:
+        return None
+    a = np.ascontiguousarray(a, dtype=np.uint32)
+    if a.size != n:
+        raise ValueError(f"world_index: {a.size} entries for {n} primitives")
+    return a
+
+
+def debug_set(name: str, value: int) -> int:
+    """Set a launch-path knob (RT_FORCE_CAPPED, RT_STACK_LDS, RT_CULL_WALK, ...: csrc/rt_api.hip DebugKnob); returns the
+    previous value.  Tests and tools only."""
+    prev = load().rt_debug_set(name.encode(), int(value))
+    if prev == -2**31:
+        raise KeyError(name)
+    return prev

@@ -47,8 +47,32 @@ def _deps() -> list[Path]:
                                             Path(__file__)]
 
 
+FLAGS_PATH = LIB_DIR / "librt_s8.flags"      # the exact compile lines of the library next to it
+
+
+def _extra_flags() -> list[str]:
+    return os.environ.get("RT_EXTRA_HIPCC_FLAGS", "").split()          # experiments only (e.g. -DRT_MAXC=12)
+
+
+def flags_record(extra: list[str] | None = None) -> str:
+    """What the library was (or would be) compiled with: one line per translation unit.  A library whose record differs
+    from the flags asked for NOW is stale whatever its mtime — an A/B script that died before restoring the default
+    build (tools/ab*.sh, phase_time.py: -DRT_PROFILE_TIME, experimental -D knobs) would otherwise leave a variant that
+    looks fresh, travels to the GPU box and gets benchmarked."""
+    extra = _extra_flags() if extra is None else extra
+    common = [f for f in HIPCC_FLAGS if f != "-shared"] + extra
+    return "".join(f"{unit}: {' '.join(common + flags)}\n" for unit, flags in UNITS)
+
+
+def built_with_default_flags() -> bool:
+    """True iff the library on disk was compiled with exactly HIPCC_FLAGS (no RT_EXTRA_HIPCC_FLAGS)."""
+    return LIB_PATH.exists() and FLAGS_PATH.exists() and FLAGS_PATH.read_text() == flags_record([])
+
+
 def needs_build() -> bool:
-    if not LIB_PATH.exists():
+    if not LIB_PATH.exists() or not FLAGS_PATH.exists():
+        return True
+    if FLAGS_PATH.read_text() != flags_record():
         return True
     t = LIB_PATH.stat().st_mtime
     return any(d.stat().st_mtime > t for d in _deps())
@@ -60,7 +84,9 @@ def build(force: bool = False, verbose: bool = False) -> Path:
         return LIB_PATH
     LIB_DIR.mkdir(parents=True, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "hipcc")
-    extra = os.environ.get("RT_EXTRA_HIPCC_FLAGS", "").split()          # experiments only (e.g. -DRT_MAXC=12)
+    extra = _extra_flags()
+    if FLAGS_PATH.exists():
+        FLAGS_PATH.unlink()                       # no record while the objects are in flux
     obj_dir = LIB_DIR / "obj"
     obj_dir.mkdir(exist_ok=True)
     common = [f for f in HIPCC_FLAGS if f != "-shared"] + extra + [f"-I{ROOT / 'include'}", f"-I{CSRC}"]
@@ -85,6 +111,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     proc = subprocess.run(cmds[-1], capture_output=True, text=True)
     if proc.returncode != 0:
         raise RuntimeError(f"hipcc link failed ({proc.returncode}):\n{proc.stdout}\n{proc.stderr}")
+    FLAGS_PATH.write_text(flags_record(extra))
     return LIB_PATH
 
 

@@ -13,6 +13,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <climits>
+#include <condition_variable>
 #include <mutex>
 #include <new>
 #include <stdexcept>
@@ -75,6 +77,41 @@ struct DeviceCtx {
     std::mutex mu;   // serialises synchronous calls on one device
 };
 
+// Test / A-B knobs of the launch path.  They used to be getenv() calls inside launch_batch and rt_render_frame — read per
+// launch from several worker threads while tests flipped them with setenv (undefined behaviour), and two of them overrode
+// explicit request flags.  Now: one process-level table of atomics, filled from the environment ONCE by the first rt_init,
+// changed afterwards only through rt_debug_set (exported, deliberately not in rt_tile.h: tests and tools only), and an
+// explicit RT_FLAG_* in the request always wins over a knob.
+enum DebugKnob {
+    DBG_LDS_TREE = 0,      // RT_LDS_TREE        0: never the LDS-resident tree engine                      (default 1)
+    DBG_CULL_WALK,         // RT_CULL_WALK       0 / 1: culled walk off / on wherever it is valid; -1: host rule (default -1)
+    DBG_NO_STAGE,          // RT_NO_STAGE        1: no LDS output staging                                   (default 0)
+    DBG_CULL_MINL,         // RT_CULL_MINL       leaf-list slots the culled walk keeps when it trades them for staging (3)
+    DBG_FORCE_CAPPED,      // RT_FORCE_CAPPED    1: quantised walks take the capped-stack kernel             (default 0)
+    DBG_STACK_LDS,         // RT_STACK_LDS       capped-stack kernel: stack entries per lane in LDS; 0: STACK_LDS_MAX
+    DBG_COMPACT,           // RT_COMPACT         0: per-lane root tests in the exact-node L2 kernel          (default 1)
+    DBG_REFILL_EIGHTHS,    // RT_REFILL_EIGHTHS  refill threshold of the walks; 0: host rule
+    DBG_TILE_8X8,          // RT_TILE_SHAPE=8x8  square tiles                                               (default 0)
+    DBG_VERBOSE,           // RT_VERBOSE         engine / LDS plan of every launch on stderr                 (default 0)
+    DBG_N
+};
+std::atomic<int> g_dbg[DBG_N];
+const struct { const char* env; int def; } g_dbg_spec[DBG_N] = {
+    {"RT_LDS_TREE", 1}, {"RT_CULL_WALK", -1}, {"RT_NO_STAGE", 0}, {"RT_CULL_MINL", 3}, {"RT_FORCE_CAPPED", 0},
+    {"RT_STACK_LDS", 0}, {"RT_COMPACT", 1}, {"RT_REFILL_EIGHTHS", 0}, {"RT_TILE_SHAPE", 0}, {"RT_VERBOSE", 0}};
+std::once_flag g_dbg_once;
+void dbg_load_env() {
+    std::call_once(g_dbg_once, [] {
+        for (int k = 0; k < DBG_N; k++) {
+            const char* e = getenv(g_dbg_spec[k].env);
+            int v = g_dbg_spec[k].def;
+            if (e) v = k == DBG_TILE_8X8 ? (strcmp(e, "8x8") == 0) : k == DBG_VERBOSE ? 1 : atoi(e);
+            g_dbg[k].store(v, std::memory_order_relaxed);
+        }
+    });
+}
+inline int dbg(DebugKnob k) { return g_dbg[k].load(std::memory_order_relaxed); }
+
 std::mutex g_mu;
 bool g_init = false;
 std::vector<DeviceCtx*> g_ctx;
@@ -123,6 +160,8 @@ struct rt_scene {
     bool quant_ok = false;         // quantised walk usable and worthwhile (grid step small against the primitives)
     uint32_t root_ref = 0, bvh_depth = 0, n_internal = 0;
     uint32_t* d_leaf_of = nullptr;
+    uint32_t* d_world_rank = nullptr;   // world_index of every primitive when the caller gave one (rt_tile.h "the world's order")
+    bool has_order = false;
     float bvh_build_ms = 0.f;
     unsigned long long* d_counters = nullptr;   // [0..2] stats, [4 + slot] tile queues
     // staging for the host-buffer entry point (grown on demand)
@@ -242,7 +281,7 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     // LDS-resident tree (engine 4, kernel variant 3): the exact 64-byte nodes of a small scene staged into LDS by one
     // 1024-thread workgroup per CU, 16-bit references / stack / leaf lists.  RT_FLAG_NO_LDS_TREE forces the
     // L2-gather kernel (A/B runs, tests).
-    static const bool ltree_env = [] { const char* e = getenv("RT_LDS_TREE"); return !e || atoi(e) != 0; }();
+    const bool ltree_env = dbg(DBG_LDS_TREE) != 0;
     bool ltree_fits = false;
     const size_t lt_lane = ((size_t)rtk::MAXL_LTREE + (size_t)(rq->max_bounces + 1) + (size_t)(sc->bvh_depth + 2)) * sizeof(uint16_t);
     if (traverse && ltree_env && !(rq->flags & RT_FLAG_NO_LDS_TREE) && sc->n_internal > 0 && n_prims <= 0x7fffu &&
@@ -262,14 +301,15 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     // skipped.  Spheres only (the bound is derived from the sphere root test's error terms).
     // Default where the host heuristic says it pays (cull_pays: DESIGN.md 4.7); RT_FLAG_CULL_WALK / RT_FLAG_NO_CULL_WALK
     // force it on / off (A/B runs, tests), RT_CULL_WALK=0/1 likewise for a whole process.
-    static const int cull_env = [] { const char* e = getenv("RT_CULL_WALK"); return e ? atoi(e) : -1; }();
-    const bool cull_want = cull_env >= 0 ? cull_env != 0
-                           : (rq->flags & RT_FLAG_NO_CULL_WALK) ? false : ((rq->flags & RT_FLAG_CULL_WALK) != 0 || sc->cull_pays);
+    // (an explicit request flag wins over the process-level knob, the knob over the host rule)
+    const int cull_env = dbg(DBG_CULL_WALK);
+    const bool cull_want = (rq->flags & RT_FLAG_NO_CULL_WALK) ? false : (rq->flags & RT_FLAG_CULL_WALK) ? true
+                           : cull_env >= 0 ? cull_env != 0 : sc->cull_pays;
     const bool cull = qnodes && cull_want && sc->n_tri == 0 && std::isfinite(sc->r_slack);
     // ... and over the exact nodes (kernel variant 7): scenes with triangles — the bound of cull_bound_tri — wherever the exact-node
     // L2 walk is the engine; default where the host heuristic says it pays (xcull_pays), forced by the same flags
-    const bool xcull_want = cull_env >= 0 ? cull_env != 0
-                            : (rq->flags & RT_FLAG_NO_CULL_WALK) ? false : ((rq->flags & RT_FLAG_CULL_WALK) != 0 || sc->xcull_pays);
+    const bool xcull_want = (rq->flags & RT_FLAG_NO_CULL_WALK) ? false : (rq->flags & RT_FLAG_CULL_WALK) ? true
+                            : cull_env >= 0 ? cull_env != 0 : sc->xcull_pays;
     const bool xcull = traverse && !qnodes && !ltree && xcull_want && sc->n_tri > 0 && sc->tri_ok && std::isfinite(sc->r_slack) &&
                        !sc->inverted_boxes;
     const bool streamed = !traverse && sc->n_sph_pad > RESIDENT_MAX;
@@ -288,8 +328,7 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     // stack slots per lane: up to bvh_depth pending right children (+ 1 spare); the LDS-tree kernel's branch-free step
     // adds the DONE sentinel in slot 0 and needs the free slot its unconditional stores land in
     // output staging (rtk::STAGE_SLOTS tiles per wave): wherever the LDS plan has room for it
-    const bool want_stage = [] { const char* e = getenv("RT_NO_STAGE"); return !(e && atoi(e) != 0); }() &&
-                            ((traverse && !ltree) || streamed);     // the kernels it is compiled into (see there)
+    const bool want_stage = dbg(DBG_NO_STAGE) == 0 && ((traverse && !ltree) || streamed);     // the kernels it is compiled into (see there)
     const bool list16 = traverse && !ltree && n_prims <= 65536u;          // 16-bit leaf-list entries: half the LDS
     size_t stage_bytes_wg = (size_t)rtk::STAGE_BYTES * ((ltree ? rtk::LTREE_BLOCK : rtk::BLOCK) / 64);
     uint32_t stage_slots = rtk::STAGE_SLOTS;
@@ -303,7 +342,7 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
         // the culled walk needs short leaf lists only (its candidates are few and tested early), so it trades list slots for
         // staging slots: every tile that finds no free staging slot is stored byte by byte and written back many times over
         // (c5 WRITE_SIZE: 3 slots 1.42 x the frame)
-        static const uint32_t cull_minl = [] { const char* e = getenv("RT_CULL_MINL"); return e ? (uint32_t)atoi(e) : 3u; }();
+        const uint32_t cull_minl = (uint32_t)std::max(1, dbg(DBG_CULL_MINL));
         if (want_stage && cull) {
             const size_t base = path_bytes + (size_t)stack_need * rtk::BLOCK * sizeof(uint32_t);
             for (uint32_t s_ = rtk::STAGE_SLOTS_MAX; s_ > rtk::STAGE_SLOTS; s_--)
@@ -314,12 +353,12 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
                 }
         }
         const size_t fixed = path_bytes + (size_t)stack_need * rtk::BLOCK * sizeof(uint32_t) + (want_stage ? stage_bytes_wg : 0);
-        // (RT_FORCE_CAPPED / RT_STACK_LDS, read per launch: tests drive the capped-stack kernel with small trees)
-        const bool force_capped = [] { const char* e = getenv("RT_FORCE_CAPPED"); return e && atoi(e) != 0; }();
+        // (DBG_FORCE_CAPPED / DBG_STACK_LDS: tests drive the capped-stack kernel with small trees)
+        const bool force_capped = dbg(DBG_FORCE_CAPPED) != 0;
         if (!force_capped && fixed + (size_t)(stage_slots > rtk::STAGE_SLOTS ? cull_minl : (uint32_t)rtk::MINL) * slot <= per_wg) {
             maxl = (uint32_t)std::min<size_t>((size_t)rtk::MAXL, (per_wg - fixed) / slot);
         } else {
-            const uint32_t cap = [] { const char* e = getenv("RT_STACK_LDS"); return e && atoi(e) > 0 ? (uint32_t)atoi(e) : STACK_LDS_MAX; }();
+            const uint32_t cap = dbg(DBG_STACK_LDS) > 0 ? (uint32_t)dbg(DBG_STACK_LDS) : STACK_LDS_MAX;
             capped = stack_capped > cap;
             stack_lds = capped ? cap : stack_need;
         }
@@ -352,7 +391,7 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     }
     // compacted root tests of the exact-node L2 kernel (1 KiB per wave; RT_COMPACT=0 keeps the per-lane flush for A/B runs)
     p.lds_cmp_off = 0xffffffffu;
-    static const bool compact_env = [] { const char* e = getenv("RT_COMPACT"); return !e || atoi(e) != 0; }();
+    const bool compact_env = dbg(DBG_COMPACT) != 0;
     if (traverse && !qnodes && !ltree && compact_env && lds + 1024u * (rtk::BLOCK / 64) + 16 <= LDS_LIMIT) {
         lds = (lds + 15) & ~(size_t)15;
         p.lds_cmp_off = (uint32_t)lds;
@@ -391,15 +430,16 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     {
         // refill threshold: long walks (large scenes) want finished lanes replaced sooner, short walks amortise the
         // per-round shading / ray-generation code over more finished lanes (tools/variants_q.sh sweeps)
-        static const int forced = [] { const char* e = getenv("RT_REFILL_EIGHTHS"); return e ? atoi(e) : 0; }();
+        const int forced = dbg(DBG_REFILL_EIGHTHS);
         p.refill_eighths = forced > 0 ? (uint32_t)forced : (n_prims >= RT_QNODES_MIN_PRIMS ? 4u : 2u);
     }
     p.leaf_of = sc->d_leaf_of;
+    p.world_rank = sc->has_order ? sc->d_world_rank : nullptr;
     p.n_strips = n;
     // Tile shape: 64x1 keeps each tile row on whole 64-byte lines of the RGB8 strip (64 px * 3 B = 3 lines),
     // so one CU / one XCD L2 writes every byte of a line; 8x8 tiles split lines across XCDs and doubled the
     // HBM write traffic (profiles/).  RT_TILE_SHAPE=8x8 restores square tiles for A/B runs.
-    static const bool square = [] { const char* e = getenv("RT_TILE_SHAPE"); return e && !strcmp(e, "8x8"); }();
+    const bool square = dbg(DBG_TILE_8X8) != 0;
     p.tile_wlog2 = (!square && p.W >= 64) ? 6u : 3u;
     const uint32_t tw = 1u << p.tile_wlog2, th = 64u >> p.tile_wlog2;
     p.tiles_x = (p.W + tw - 1) / tw;
@@ -432,8 +472,7 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     const rtk::KernelFn kern = traverse ? rtk::kernel_traverse(ltree ? 3 : qnodes ? (cull_run ? (capped ? 6 : 5) : capped ? 2 : 1) : xcull ? 7 : 0, count_steps) : rtk::kernel_linear(streamed, expanded);
     HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, bs, lds));
     if (per_cu < 1) per_cu = 1;
-    static const bool verbose = getenv("RT_VERBOSE") != nullptr;
-    if (verbose)
+    if (dbg(DBG_VERBOSE))
         fprintf(stderr, "[rt] engine %d%s  lds %zu B  workgroups/CU %d  leaf slots %u  bvh depth %u  leaf density %.3f  prims %u\n",
                 traverse ? (ltree ? 4 : qnodes ? (cull_run ? 5 : 3) : xcull ? 6 : 2) : (streamed ? 1 : 0), capped ? " (capped stack)" : "", lds, per_cu, maxl,
                 sc->bvh_depth, sc->leaf_density, n_prims);
@@ -561,6 +600,7 @@ RT_API size_t rt_tile_bytes(const rt_tile_request* rq) {
 }
 
 static int rt_init_impl(int* n_devices) {
+    dbg_load_env();
     std::lock_guard<std::mutex> lk(g_mu);
     if (g_init) {
         if (n_devices) *n_devices = (int)g_ctx.size();
@@ -643,18 +683,33 @@ struct HostScene {
     bool xcull_pays = false;         // a scene with triangles that the culled walk over the exact nodes may take, and where it pays
     bool tri_ok = false;             //   ... may take at all (every triangle has a finite bound or a place in the list)
     float cull_density = 0.f;        // sum of the other spheres' box areas / area of the box around them
+    std::vector<uint32_t> world_rank;   // the caller's world_index (one dummy entry when none came)
+    bool has_order = false;
 };
 
-static int check_world(const rt_sphere* sp, uint32_t ns, const rt_triangle* tr, uint32_t nt) {
+static int check_world(const rt_sphere* sp, uint32_t ns, const rt_triangle* tr, uint32_t nt, const uint32_t* world_index) {
     if ((ns && !sp) || (nt && !tr)) return fail(RT_ERR_BAD_ARG, "primitive pointer is NULL");
     // the kernels address nodes (64 B), geometry (16 B), materials (16 B) and triangles (36 B) with 32-bit byte offsets
     if ((uint64_t)ns + nt > RT_MAX_PRIMITIVES) return fail(RT_ERR_LIMIT, "too many primitives (RT_MAX_PRIMITIVES)");
+    if (world_index) {                   // positions in RenderInfo.world: every one of 0 .. n - 1 exactly once
+        const uint32_t np = ns + nt;
+        std::vector<bool> seen(np, false);
+        for (uint32_t i = 0; i < np; i++) {
+            if (world_index[i] >= np || seen[world_index[i]])
+                return fail(RT_ERR_BAD_ARG, "world_index is not a permutation of 0 .. n_spheres + n_triangles - 1");
+            seen[world_index[i]] = true;
+        }
+    }
     return RT_OK;
 }
 
-static void build_host_scene(const rt_sphere* sp, uint32_t ns, const rt_triangle* tr, uint32_t nt, HostScene& hs) {
+static void build_host_scene(const rt_sphere* sp, uint32_t ns, const rt_triangle* tr, uint32_t nt, const uint32_t* world_index,
+                             HostScene& hs) {
     hs.ns = ns;
     hs.nt = nt;
+    hs.has_order = world_index != nullptr && ns + nt > 0;
+    if (hs.has_order) hs.world_rank.assign(world_index, world_index + ns + nt);
+    else hs.world_rank.assign(1, 0u);
     hs.n_sph_pad = (ns + rtk::UNROLL - 1) / rtk::UNROLL * rtk::UNROLL;
     const uint32_t np = ns + nt;
     std::vector<float4>& geom = hs.geom;
@@ -747,7 +802,16 @@ static void build_host_scene(const rt_sphere* sp, uint32_t ns, const rt_triangle
         hs.tri_box[2 * (size_t)i + 1] = make_float4(b.hi[0], b.hi[1], b.hi[2], 0.f);
     }
     auto tb0 = std::chrono::steady_clock::now();
-    hs.bvh = rtbvh::build(boxes);
+    {
+        // BVH::build(&mut req.world) (slave main.rs:60) numbers the shapes by their position in `world`: start the build
+        // from the primitives in that order (rt_bvh.h); ties between equal distances then fall as in the reference
+        std::vector<uint32_t> order;
+        if (hs.has_order) {
+            order.resize(np);
+            for (uint32_t i = 0; i < np; i++) order[world_index[i]] = i;
+        }
+        hs.bvh = rtbvh::build(boxes, hs.has_order ? order.data() : nullptr);
+    }
     rtbvh::FlatBVH& bvh = hs.bvh;
     hs.bvh_build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - tb0).count();
     hs.n_internal = (uint32_t)bvh.trav.size();        // before the placeholders below
@@ -969,6 +1033,8 @@ static int upload_scene(int device, const HostScene& hs, rt_scene** out) {
     SC_UP(d_tri_box, hs.tri_box);
     SC_UP(d_bvh, bvh.nodes);
     SC_UP(d_leaf_of, bvh.leaf_of);
+    SC_UP(d_world_rank, hs.world_rank);
+    sc->has_order = hs.has_order;
     SC_UP(d_trav, bvh.trav);
     SC_UP(d_travq, bvh.travq);
     SC_UP(d_geom_r, hs.geom_r);
@@ -993,7 +1059,7 @@ static int upload_scene(int device, const HostScene& hs, rt_scene** out) {
 #undef SC_CHK
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
-    if (getenv("RT_VERBOSE"))
+    if (dbg(DBG_VERBOSE))
         fprintf(stderr, "[rt] scene: %u prims  culled walk: %u big spheres, slack radius %g, box density %.3f -> %s  bvh build %.2f ms (host)  uploads %.2f ms  upload total %.2f ms\n",
                 hs.ns + hs.nt, hs.n_big, hs.r_slack, hs.cull_density, hs.cull_pays ? "default" : "off", sc->bvh_build_ms, sc->h2d_ms,
                 std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_create0).count());
@@ -1003,15 +1069,15 @@ static int upload_scene(int device, const HostScene& hs, rt_scene** out) {
 }
 
 static int rt_scene_create_impl(int device, const rt_sphere* sp, uint32_t ns, const rt_triangle* tr, uint32_t nt,
-                                rt_scene** out) {
+                                const uint32_t* world_index, rt_scene** out) {
     if (!out) return fail(RT_ERR_BAD_ARG, "out_scene is NULL");
     *out = nullptr;
-    int rc = check_world(sp, ns, tr, nt);
+    int rc = check_world(sp, ns, tr, nt, world_index);
     if (rc) return rc;
     if (!g_init) return fail(RT_ERR_NOT_INITIALIZED, "call rt_init() first");
     if (device < 0 || device >= (int)g_ctx.size()) return fail(RT_ERR_BAD_DEVICE, "bad device ordinal");
     HostScene hs;
-    build_host_scene(sp, ns, tr, nt, hs);
+    build_host_scene(sp, ns, tr, nt, world_index, hs);
     return upload_scene(device, hs, out);
 }
 
@@ -1042,6 +1108,7 @@ static int rt_scene_destroy_impl(rt_scene* sc) {
     (void)hipFree(sc->d_geom_r);
     (void)hipFree(sc->d_big);
     (void)hipFree(sc->d_leaf_of);
+    (void)hipFree(sc->d_world_rank);
     (void)hipFree(sc->d_counters);
     (void)hipFree(sc->d_out);
     (void)hipFree(sc->d_outf);
@@ -1209,22 +1276,33 @@ static int rt_scene_render_tile_impl(rt_scene* sc, const rt_tile_request* rq, ui
 // debug: raw read of the scene's device counter words (tools/phase_census.py); not part of rt_tile.h
 extern "C" __attribute__((visibility("default"))) int rt_debug_read_counters(rt_scene* sc, uint32_t first, uint32_t n,
                                                                              unsigned long long* out) {
-    if (!sc || !out || first + n > COUNTER_WORDS) return RT_ERR_BAD_ARG;
-    if (hipSetDevice(sc->ctx->dev) != hipSuccess) return RT_ERR_HIP;
-    if (hipMemcpy(out, sc->d_counters + first, n * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess)
-        return RT_ERR_HIP;
-    return RT_OK;
+    return guarded([&]() -> int {
+        if (!sc || !out || first > COUNTER_WORDS || n > COUNTER_WORDS - first) return fail(RT_ERR_BAD_ARG, "counter range");
+        std::lock_guard<std::mutex> lk(sc->mu);
+        HIPCHK(hipSetDevice(sc->ctx->dev));
+        HIPCHK(hipMemcpy(out, sc->d_counters + first, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        return RT_OK;
+    });
+}
+// debug: set one knob of the launch path (DebugKnob above) by its environment-variable name; returns the previous value,
+// INT_MIN for an unknown name.  Tests and tools only; not part of rt_tile.h.
+extern "C" __attribute__((visibility("default"))) int rt_debug_set(const char* name, int value) {
+    dbg_load_env();
+    if (!name) return INT32_MIN;
+    for (int k = 0; k < DBG_N; k++)
+        if (!strcmp(name, g_dbg_spec[k].env)) return g_dbg[k].exchange(value);
+    return INT32_MIN;
 }
 
 static int rt_render_tile_impl(int device, const rt_tile_request* rq, const rt_sphere* sp, uint32_t ns,
-                          const rt_triangle* tr, uint32_t nt, uint8_t* out_rgb, size_t out_len, float* out_f32,
-                          rt_tile_stats* stats) {
+                          const rt_triangle* tr, uint32_t nt, const uint32_t* world_index, uint8_t* out_rgb, size_t out_len,
+                          float* out_f32, rt_tile_stats* stats) {
     int rc = check_request(rq);
     if (rc) return rc;
     if (!out_rgb) return fail(RT_ERR_BAD_ARG, "out_rgb is NULL");
     if (out_len < rt_tile_bytes(rq)) return fail(RT_ERR_BUFFER_TOO_SMALL, "out_len < (H/div)*W*3");
     rt_scene* sc = nullptr;
-    rc = rt_scene_create_impl(device, sp, ns, tr, nt, &sc);
+    rc = rt_scene_create_impl(device, sp, ns, tr, nt, world_index, &sc);
     if (rc) return rc;
     rc = rt_scene_render_tile_impl(sc, rq, out_rgb, out_len, out_f32, stats);
     std::string keep = g_err;
@@ -1233,23 +1311,223 @@ static int rt_render_tile_impl(int device, const rt_tile_request* rq, const rt_s
     return rc;
 }
 
-static int rt_render_frame_impl(const int* devices, int n_devices, const rt_tile_request* rq_in, const rt_sphere* sp,
-                                uint32_t ns, const rt_triangle* tr, uint32_t nt, uint8_t* out_rgb, size_t out_len,
-                                rt_tile_stats* stats) {
-    if (!rq_in) return fail(RT_ERR_BAD_ARG, "request is NULL");
-    rt_tile_request rq0 = *rq_in;
-    rq0.division_no = 0;
-    int rc = check_request(&rq0);
-    if (rc) return rc;
-    if (!out_rgb) return fail(RT_ERR_BAD_ARG, "out_rgb is NULL");
-    rc = check_world(sp, ns, tr, nt);
-    if (rc) return rc;
+// =====================================================================================
+// Frame context: the controller's dispatch + assembly (controller main.rs:47-75, 109-115) with everything a JOB needs kept
+// alive between frames — one dispatcher thread per device entry, the world resident on every device, streams, strip
+// buffers, and the page-locked registration of the caller's frame buffer.
+// =====================================================================================
+}  // extern "C"  (the struct below is a C++ type behind the opaque C handle)
+
+struct FrameDev {
+    int dev = 0;                        // device ordinal
+    rt_scene* scene = nullptr;          // the job's world on this device (owned by the dispatcher thread)
+    std::thread th;
+    // strip-queue mode: two strips in flight, each on its own stream with its own device buffer (made on first use)
+    hipStream_t qs[2] = {nullptr, nullptr};
+    uint8_t* qd[2] = {nullptr, nullptr};
+    size_t qcap = 0;
+    // result of the last command
+    int rc = RT_OK;
+    std::string err;
+    rt_tile_stats st;
+    float busy_ms = 0.f;                // dispatcher wall time of the last render
+};
+
+struct rt_frame_ctx {
+    std::vector<FrameDev> fd;
+    std::mutex call_mu;                 // one API call at a time per context
+    std::mutex mu;                      // command hand-over
+    std::condition_variable cv_work, cv_done;
+    uint64_t gen = 0;
+    int pending = 0;
+    enum Cmd { CMD_NONE, CMD_UPLOAD, CMD_RENDER, CMD_STOP } cmd = CMD_NONE;
+    // CMD_UPLOAD
+    const HostScene* hs = nullptr;
+    bool have_world = false;
+    float scene_ms_pending = 0.f;       // duration of the last set_world, charged to the next frame's stats
+    // CMD_RENDER
+    rt_tile_request rq;
+    uint8_t* out = nullptr;
+    size_t strip = 0;
+    bool use_queue = false;
+    std::atomic<uint32_t> next_strip{0};
+    // the caller's frame buffer, page-locked once
+    void* pinned_ptr = nullptr;
+    size_t pinned_len = 0;
+};
+
+namespace {
+
+int frame_dev_render(rt_frame_ctx* fc, int w) {
+    FrameDev& d = fc->fd[w];
+    const int nd = (int)fc->fd.size();
+    const rt_tile_request& rq0 = fc->rq;
+    const size_t strip = fc->strip;
+    uint8_t* out_rgb = fc->out;
+    std::memset(&d.st, 0, sizeof d.st);
+    rt_scene* sc = d.scene;
+    if (!sc) return fail(RT_ERR_BAD_ARG, "rt_frame_ctx_render before rt_frame_ctx_set_world");
+    if (!fc->use_queue) {
+        // strip k -> entry k % nd (controller main.rs:47-75 fires one request per division; Docker DNS round-robins them
+        // over the slaves): all strips of this device go out as one batch (one launch per <= MAX_BATCH strips, the last
+        // quarter as its own launch so that the downloads of the others run under it); stitch by division_no: strip k
+        // lands at byte offset k * strip (controller main.rs:109-115)
+        std::vector<rt_tile_request> rqs;
+        std::vector<uint8_t*> outs;
+        for (uint32_t k = (uint32_t)w; k < rq0.divisions; k += (uint32_t)nd) {
+            rt_tile_request rq = rq0;
+            rq.division_no = k;
+            rqs.push_back(rq);
+            outs.push_back(out_rgb + (size_t)k * strip);
+        }
+        if (rqs.empty()) return RT_OK;
+        return rt_scene_render_tiles_impl(sc, rqs.data(), (uint32_t)rqs.size(), outs.data(), strip, nullptr, &d.st);
+    }
+    // ---- dynamic assignment: pull one strip at a time, the bottom of the frame first (its strips cost the most:
+    // longest-first keeps the devices' finish times within one cheap strip of each other).  Two strips in flight per
+    // entry, each on its own stream with its own device buffer: the launch tail and the download of one run under
+    // the other.  Streams and buffers belong to the context: made on the first queue-mode frame, grown when a frame
+    // has larger strips.
+    DeviceCtx* ctx = sc->ctx;
+    HIPCHK(hipSetDevice(ctx->dev));
+    for (int i = 0; i < 2; i++)
+        if (!d.qs[i]) HIPCHK(hipStreamCreateWithFlags(&d.qs[i], hipStreamNonBlocking));
+    if (d.qcap < strip) {
+        for (int i = 0; i < 2; i++) {
+            (void)hipFree(d.qd[i]);
+            d.qd[i] = nullptr;
+        }
+        d.qcap = 0;
+        for (int i = 0; i < 2; i++)
+            if (hipMalloc(&d.qd[i], strip) != hipSuccess) return fail(RT_ERR_OOM, "hipMalloc(strip) failed");
+        d.qcap = strip;
+    }
+    bool busy[2] = {false, false};
+    struct Settle {                       // an error return waits for what is already enqueued (it writes caller memory)
+        FrameDev& d;
+        bool* busy;
+        ~Settle() {
+            for (int i = 0; i < 2; i++)
+                if (busy[i]) (void)hipStreamSynchronize(d.qs[i]);
+        }
+    } settle{d, busy};
+    for (uint32_t turn = 0;; turn++) {
+        const int sl = (int)(turn & 1u);
+        if (busy[sl]) {
+            HIPCHK(hipStreamSynchronize(d.qs[sl]));
+            busy[sl] = false;
+        }
+        const uint32_t i = fc->next_strip.fetch_add(1);
+        if (i >= rq0.divisions) break;
+        rt_tile_request rq = rq0;
+        rq.division_no = rq0.divisions - 1u - i;
+        void* d1[1] = {d.qd[sl]};
+        int r = rt_scene_render_tiles_device_impl(sc, &rq, 1, d1, strip, nullptr, d.qs[sl]);
+        if (r) return r;
+        HIPCHK(hipMemcpyAsync(out_rgb + (size_t)rq.division_no * strip, d.qd[sl], strip, hipMemcpyDeviceToHost, d.qs[sl]));
+        busy[sl] = true;
+    }
+    for (int i = 0; i < 2; i++)
+        if (busy[i]) {
+            HIPCHK(hipStreamSynchronize(d.qs[i]));
+            busy[i] = false;
+        }
+    return rt_scene_collect_impl(sc, &d.st);
+}
+
+void frame_dev_release(FrameDev& d) {
+    if (d.scene) {
+        rt_scene_destroy_impl(d.scene);       // (sets the scene's device current)
+        d.scene = nullptr;
+    } else {
+        (void)hipSetDevice(d.dev);
+    }
+    for (int i = 0; i < 2; i++) {
+        if (d.qs[i]) {
+            (void)hipStreamSynchronize(d.qs[i]);
+            (void)hipStreamDestroy(d.qs[i]);
+            d.qs[i] = nullptr;
+        }
+        (void)hipFree(d.qd[i]);
+        d.qd[i] = nullptr;
+    }
+    d.qcap = 0;
+}
+
+// dispatcher thread of entry w: sleeps on the context's condition variable between commands
+void frame_dev_main(rt_frame_ctx* fc, int w) {
+    FrameDev& d = fc->fd[w];
+    uint64_t seen = 0;
+    for (;;) {
+        rt_frame_ctx::Cmd cmd;
+        {
+            std::unique_lock<std::mutex> lk(fc->mu);
+            fc->cv_work.wait(lk, [&] { return fc->gen != seen; });
+            seen = fc->gen;
+            cmd = fc->cmd;
+        }
+        // an exception must not leave a thread function (std::terminate): same guard as the entry points
+        const auto t0 = std::chrono::steady_clock::now();
+        d.rc = guarded([&]() -> int {
+            switch (cmd) {
+                case rt_frame_ctx::CMD_UPLOAD: {
+                    if (d.scene) {
+                        rt_scene_destroy_impl(d.scene);
+                        d.scene = nullptr;
+                    }
+                    return upload_scene(d.dev, *fc->hs, &d.scene);     // world uploaded once per device per job
+                }
+                case rt_frame_ctx::CMD_RENDER: return frame_dev_render(fc, w);
+                case rt_frame_ctx::CMD_STOP: frame_dev_release(d); return RT_OK;
+                default: return RT_OK;
+            }
+        });
+        d.busy_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (d.rc) {
+            try {
+                d.err = g_err;
+            } catch (...) {
+            }
+        }
+        {
+            std::lock_guard<std::mutex> lk(fc->mu);
+            if (--fc->pending == 0) fc->cv_done.notify_all();
+        }
+        if (cmd == rt_frame_ctx::CMD_STOP) return;
+    }
+}
+
+// hand one command to every dispatcher and wait for all of them; the first error (in entry order) is the call's
+int frame_run(rt_frame_ctx* fc, rt_frame_ctx::Cmd cmd) {
+    {
+        std::lock_guard<std::mutex> lk(fc->mu);
+        fc->cmd = cmd;
+        fc->pending = (int)fc->fd.size();
+        fc->gen++;
+    }
+    fc->cv_work.notify_all();
+    {
+        std::unique_lock<std::mutex> lk(fc->mu);
+        fc->cv_done.wait(lk, [&] { return fc->pending == 0; });
+    }
+    for (FrameDev& d : fc->fd)
+        if (d.rc) return fail(d.rc, d.err);
+    return RT_OK;
+}
+
+void frame_unpin(rt_frame_ctx* fc) {
+    if (fc->pinned_ptr) {
+        if (!fc->fd.empty()) (void)hipSetDevice(fc->fd[0].dev);
+        (void)hipHostUnregister(fc->pinned_ptr);
+        fc->pinned_ptr = nullptr;
+        fc->pinned_len = 0;
+    }
+}
+
+int rt_frame_ctx_create_impl(const int* devices, int n_devices, rt_frame_ctx** out) {
+    if (!out) return fail(RT_ERR_BAD_ARG, "out_ctx is NULL");
+    *out = nullptr;
     if (!g_init) return fail(RT_ERR_NOT_INITIALIZED, "call rt_init() first");
-    // the controller's ImageBuffer::from_vec(width, height, ..).unwrap() (controller main.rs:117-119)
-    // panics unless the strips tile the frame exactly
-    if (rq0.height % rq0.divisions != 0) return fail(RT_ERR_FRAME_SIZE, "height % divisions != 0");
-    const size_t strip = rt_tile_bytes(&rq0);
-    if (out_len < strip * rq0.divisions) return fail(RT_ERR_BUFFER_TOO_SMALL, "out_len < H*W*3");
     std::vector<int> devs;
     if (devices && n_devices > 0)
         devs.assign(devices, devices + n_devices);
@@ -1257,144 +1535,195 @@ static int rt_render_frame_impl(const int* devices, int n_devices, const rt_tile
         for (size_t d = 0; d < g_ctx.size(); d++) devs.push_back((int)d);
     for (int d : devs)
         if (d < 0 || d >= (int)g_ctx.size()) return fail(RT_ERR_BAD_DEVICE, "bad device ordinal");
-    const int nd = (int)devs.size();
-    // the world's host side once per job (the reference rebuilds the BVH per strip, slave main.rs:60)
-    HostScene hs;
-    build_host_scene(sp, ns, tr, nt, hs);
-    // page-lock the frame buffer for the call: strip downloads become DMA that runs under the kernels.  Best effort:
-    // a buffer the caller already registered (or that cannot be registered) is used as it is.
-    bool pinned = false;
-    {
-        const char* e = getenv("RT_PIN_FRAME");            // (read per call: tests and A/B runs flip it)
-        const bool pin = !e || atoi(e) != 0;
-        if (pin && hipHostRegister(out_rgb, strip * rq0.divisions, hipHostRegisterPortable) == hipSuccess) pinned = true;
-        else (void)hipGetLastError();
+    rt_frame_ctx* fc = new rt_frame_ctx;
+    fc->fd.resize(devs.size());
+    std::memset(&fc->rq, 0, sizeof fc->rq);
+    size_t started = 0;
+    try {
+        for (; started < devs.size(); started++) {
+            fc->fd[started].dev = devs[started];
+            fc->fd[started].th = std::thread(frame_dev_main, fc, (int)started);
+        }
+    } catch (...) {
+        // could not start every dispatcher: stop the ones that run (they wait for `pending` of their own count)
+        fc->fd.resize(started);
+        if (started) (void)frame_run(fc, rt_frame_ctx::CMD_STOP);
+        for (FrameDev& d : fc->fd)
+            if (d.th.joinable()) d.th.join();
+        delete fc;
+        throw;
     }
-    struct Unpin {
-        void* ptr;
-        bool on;
-        ~Unpin() {
-            if (on) (void)hipHostUnregister(ptr);
-        }
-    } unpin{out_rgb, pinned};
-    const bool use_queue = [] { const char* e = getenv("RT_FRAME_QUEUE"); return e && atoi(e) != 0; }();
-    std::atomic<uint32_t> next_strip{0};                  // RT_FRAME_QUEUE: strips handed out bottom-up
-    std::vector<int> rcs(nd, RT_OK);
-    std::vector<std::string> errs(nd);
-    std::vector<rt_tile_stats> sts(nd);
-    for (auto& st : sts) std::memset(&st, 0, sizeof st);
-    auto work = [&](int w) -> int {
-        rt_scene* sc = nullptr;
-        int r = upload_scene(devs[w], hs, &sc);           // world uploaded once per device per job
-        if (r) return r;
-        struct Destroy {
-            rt_scene* sc;
-            ~Destroy() { rt_scene_destroy_impl(sc); }
-        } destroy{sc};
-        if (!use_queue) {
-            // strip k -> devs[k % nd] (controller main.rs:47-75 fires one request per division; Docker DNS round-robins
-            // them over the slaves): all strips of this device go out as one batch (one launch per <= MAX_BATCH strips);
-            // stitch by division_no: strip k lands at byte offset k * strip (controller main.rs:109-115)
-            std::vector<rt_tile_request> rqs;
-            std::vector<uint8_t*> outs;
-            for (uint32_t k = (uint32_t)w; k < rq0.divisions; k += (uint32_t)nd) {
-                rt_tile_request rq = rq0;
-                rq.division_no = k;
-                rqs.push_back(rq);
-                outs.push_back(out_rgb + (size_t)k * strip);
-            }
-            if (rqs.empty()) return RT_OK;
-            return rt_scene_render_tiles_impl(sc, rqs.data(), (uint32_t)rqs.size(), outs.data(), strip, nullptr, &sts[w]);
-        }
-        // ---- dynamic assignment: pull one strip at a time, the bottom of the frame first (its strips cost the most:
-        // longest-first keeps the devices' finish times within one cheap strip of each other).  Two strips in flight per
-        // device, each on its own stream with its own device buffer: the launch tail and the download of one run under
-        // the other.
-        DeviceCtx* ctx = sc->ctx;
-        HIPCHK(hipSetDevice(ctx->dev));
-        struct Slot {
-            hipStream_t st = nullptr;
-            uint8_t* d = nullptr;
-            bool busy = false;
-            ~Slot() {
-                if (st) {
-                    (void)hipStreamSynchronize(st);
-                    (void)hipStreamDestroy(st);
-                }
-                (void)hipFree(d);
-            }
-        } slot[2];
-        for (auto& sl : slot) {
-            HIPCHK(hipStreamCreateWithFlags(&sl.st, hipStreamNonBlocking));
-            if (hipMalloc(&sl.d, strip) != hipSuccess) return fail(RT_ERR_OOM, "hipMalloc(strip) failed");
-        }
-        for (uint32_t turn = 0;; turn++) {
-            Slot& sl = slot[turn & 1];
-            if (sl.busy) {
-                HIPCHK(hipStreamSynchronize(sl.st));
-                sl.busy = false;
-            }
-            const uint32_t i = next_strip.fetch_add(1);
-            if (i >= rq0.divisions) break;
-            rt_tile_request rq = rq0;
-            rq.division_no = rq0.divisions - 1u - i;
-            void* d1[1] = {sl.d};
-            r = rt_scene_render_tiles_device_impl(sc, &rq, 1, d1, strip, nullptr, sl.st);
-            if (r) return r;
-            HIPCHK(hipMemcpyAsync(out_rgb + (size_t)rq.division_no * strip, sl.d, strip, hipMemcpyDeviceToHost, sl.st));
-            sl.busy = true;
-        }
-        for (auto& sl : slot)
-            if (sl.busy) HIPCHK(hipStreamSynchronize(sl.st));
-        return rt_scene_collect_impl(sc, &sts[w]);
-    };
-    {
-        std::vector<std::thread> th;
-        struct Join {
-            std::vector<std::thread>& th;
-            ~Join() {
-                for (auto& t : th)
-                    if (t.joinable()) t.join();
-            }
-        } join{th};
-        th.reserve(nd);
-        // an exception must not leave a thread function either (std::terminate): same guard as the entry points
-        for (int w = 0; w < nd; w++)
-            th.emplace_back([&, w] {
-                rcs[w] = guarded([&] { return work(w); });
-                if (rcs[w]) {
-                    try {
-                        errs[w] = g_err;
-                    } catch (...) {
-                    }
-                }
-            });
-    }
-    rt_tile_stats tot;
-    std::memset(&tot, 0, sizeof tot);
-    for (int w = 0; w < nd; w++) {
-        if (rcs[w]) return fail(rcs[w], errs[w]);
-        tot.ray_segments += sts[w].ray_segments;
-        tot.primary_rays += sts[w].primary_rays;
-        tot.broad_candidates += sts[w].broad_candidates;
-        tot.exact_fallbacks += sts[w].exact_fallbacks;
-        tot.node_steps += sts[w].node_steps;
-        tot.kernel_ms = std::max(tot.kernel_ms, sts[w].kernel_ms);   // devices run concurrently
-        tot.h2d_ms = std::max(tot.h2d_ms, sts[w].h2d_ms);
-        tot.d2h_ms = std::max(tot.d2h_ms, sts[w].d2h_ms);
-        tot.n_launches += sts[w].n_launches;
-        tot.engine = sts[w].engine;
-        tot.broad_form = sts[w].broad_form;
-    }
-    if (stats) *stats = tot;
+    *out = fc;
     return RT_OK;
 }
+
+int rt_frame_ctx_destroy_impl(rt_frame_ctx* fc) {
+    if (!fc) return RT_OK;
+    {
+        std::lock_guard<std::mutex> call(fc->call_mu);
+        (void)frame_run(fc, rt_frame_ctx::CMD_STOP);          // every dispatcher releases its world, streams and buffers
+        for (FrameDev& d : fc->fd)
+            if (d.th.joinable()) d.th.join();
+        frame_unpin(fc);
+    }
+    delete fc;
+    return RT_OK;
+}
+
+int rt_frame_ctx_set_world_impl(rt_frame_ctx* fc, const rt_sphere* sp, uint32_t ns, const rt_triangle* tr, uint32_t nt,
+                                const uint32_t* world_index) {
+    if (!fc) return fail(RT_ERR_BAD_ARG, "ctx is NULL");
+    int rc = check_world(sp, ns, tr, nt, world_index);
+    if (rc) return rc;
+    if (!g_init) return fail(RT_ERR_NOT_INITIALIZED, "call rt_init() first");
+    std::lock_guard<std::mutex> call(fc->call_mu);
+    const auto t0 = std::chrono::steady_clock::now();
+    // the world's host side once per job (the reference rebuilds the BVH per strip, slave main.rs:60)
+    HostScene hs;
+    build_host_scene(sp, ns, tr, nt, world_index, hs);
+    fc->hs = &hs;
+    fc->have_world = false;
+    rc = frame_run(fc, rt_frame_ctx::CMD_UPLOAD);
+    fc->hs = nullptr;
+    if (rc) return rc;
+    fc->have_world = true;
+    fc->scene_ms_pending = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return RT_OK;
+}
+
+int rt_frame_ctx_render_impl(rt_frame_ctx* fc, const rt_tile_request* rq_in, uint8_t* out_rgb, size_t out_len,
+                             rt_frame_stats* stats) {
+    if (!fc) return fail(RT_ERR_BAD_ARG, "ctx is NULL");
+    if (!rq_in) return fail(RT_ERR_BAD_ARG, "request is NULL");
+    rt_tile_request rq0 = *rq_in;
+    rq0.division_no = 0;
+    int rc = check_request(&rq0);
+    if (rc) return rc;
+    if (!out_rgb) return fail(RT_ERR_BAD_ARG, "out_rgb is NULL");
+    // the controller's ImageBuffer::from_vec(width, height, ..).unwrap() (controller main.rs:117-119)
+    // panics unless the strips tile the frame exactly
+    if (rq0.height % rq0.divisions != 0) return fail(RT_ERR_FRAME_SIZE, "height % divisions != 0");
+    const size_t strip = rt_tile_bytes(&rq0);
+    const size_t frame_bytes = strip * rq0.divisions;
+    if (out_len < frame_bytes) return fail(RT_ERR_BUFFER_TOO_SMALL, "out_len < H*W*3");
+    std::lock_guard<std::mutex> call(fc->call_mu);
+    if (!fc->have_world) return fail(RT_ERR_BAD_ARG, "rt_frame_ctx_render before rt_frame_ctx_set_world");
+    const auto t0 = std::chrono::steady_clock::now();
+    // page-lock the frame buffer ONCE: strip downloads become DMA that runs under the kernels.  The registration is kept
+    // until another buffer comes (or release / destroy).  Best effort: a buffer the caller registered itself (or that
+    // cannot be registered) is used as it is.
+    float pin_ms = 0.f;
+    const bool want_pin = !(rq0.flags & RT_FLAG_FRAME_NO_PIN);
+    if (!want_pin || fc->pinned_ptr != (void*)out_rgb || fc->pinned_len < frame_bytes) {
+        if (fc->pinned_ptr && !(want_pin && fc->pinned_ptr == (void*)out_rgb && fc->pinned_len >= frame_bytes)) frame_unpin(fc);
+        if (want_pin) {
+            (void)hipSetDevice(fc->fd[0].dev);                 // (not device 0 by accident: the context may exclude it)
+            if (hipHostRegister(out_rgb, frame_bytes, hipHostRegisterPortable) == hipSuccess) {
+                fc->pinned_ptr = out_rgb;
+                fc->pinned_len = frame_bytes;
+            } else {
+                (void)hipGetLastError();
+            }
+            pin_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        }
+    }
+    rq0.flags &= ~(uint32_t)(RT_FLAG_FRAME_QUEUE | RT_FLAG_FRAME_NO_PIN);   // frame-level: not the kernels' business
+    fc->rq = rq0;
+    fc->out = out_rgb;
+    fc->strip = strip;
+    fc->use_queue = (rq_in->flags & RT_FLAG_FRAME_QUEUE) != 0;
+    fc->next_strip.store(0);
+    rc = frame_run(fc, rt_frame_ctx::CMD_RENDER);
+    if (rc) return rc;
+    rt_frame_stats fs;
+    std::memset(&fs, 0, sizeof fs);
+    rt_tile_stats& tot = fs.totals;
+    float last = -1.f;
+    for (const FrameDev& d : fc->fd) {
+        tot.ray_segments += d.st.ray_segments;
+        tot.primary_rays += d.st.primary_rays;
+        tot.broad_candidates += d.st.broad_candidates;
+        tot.exact_fallbacks += d.st.exact_fallbacks;
+        tot.node_steps += d.st.node_steps;
+        tot.kernel_ms = std::max(tot.kernel_ms, d.st.kernel_ms);   // devices run concurrently
+        tot.h2d_ms = std::max(tot.h2d_ms, d.st.h2d_ms);
+        tot.d2h_ms = std::max(tot.d2h_ms, d.st.d2h_ms);
+        tot.n_launches += d.st.n_launches;
+        if (d.st.n_launches) {
+            tot.engine = d.st.engine;
+            tot.broad_form = d.st.broad_form;
+        }
+        if (d.busy_ms > last) {                                     // the entry that finished last
+            last = d.busy_ms;
+            // strip-queue mode keeps two launches in flight per entry, so their event times overlap and do not add up
+            // to a duration: there kernel_ms is the dispatcher's wall time and nothing is booked as exposed download
+            fs.kernel_ms = fc->use_queue ? d.busy_ms : d.st.kernel_ms;
+            fs.d2h_exposed_ms = fc->use_queue ? 0.f : d.st.d2h_ms;
+        }
+    }
+    fs.wall_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    fs.pin_ms = pin_ms;
+    fs.scene_ms = fc->scene_ms_pending;
+    fc->scene_ms_pending = 0.f;
+    fs.host_ms = fs.wall_ms - fs.pin_ms - fs.kernel_ms - fs.d2h_exposed_ms;
+    fs.n_devices = (uint32_t)fc->fd.size();
+    fs.pinned = fc->pinned_ptr == (void*)out_rgb ? 1u : 0u;
+    if (stats) *stats = fs;
+    return RT_OK;
+}
+
+int rt_frame_ctx_release_buffer_impl(rt_frame_ctx* fc) {
+    if (!fc) return fail(RT_ERR_BAD_ARG, "ctx is NULL");
+    std::lock_guard<std::mutex> call(fc->call_mu);
+    frame_unpin(fc);
+    return RT_OK;
+}
+
+int rt_render_frame_impl(const int* devices, int n_devices, const rt_tile_request* rq_in, const rt_sphere* sp,
+                         uint32_t ns, const rt_triangle* tr, uint32_t nt, const uint32_t* world_index, uint8_t* out_rgb,
+                         size_t out_len, rt_tile_stats* stats) {
+    // argument errors before any thread or upload
+    if (!rq_in) return fail(RT_ERR_BAD_ARG, "request is NULL");
+    rt_tile_request rq0 = *rq_in;
+    rq0.division_no = 0;
+    int rc = check_request(&rq0);
+    if (rc) return rc;
+    if (!out_rgb) return fail(RT_ERR_BAD_ARG, "out_rgb is NULL");
+    rc = check_world(sp, ns, tr, nt, world_index);
+    if (rc) return rc;
+    if (!g_init) return fail(RT_ERR_NOT_INITIALIZED, "call rt_init() first");
+    if (rq0.height % rq0.divisions != 0) return fail(RT_ERR_FRAME_SIZE, "height % divisions != 0");
+    if (out_len < rt_tile_bytes(&rq0) * rq0.divisions) return fail(RT_ERR_BUFFER_TOO_SMALL, "out_len < H*W*3");
+    rt_frame_ctx* fc = nullptr;
+    rc = rt_frame_ctx_create_impl(devices, n_devices, &fc);
+    if (rc) return rc;
+    struct Destroy {
+        rt_frame_ctx* fc;
+        ~Destroy() {
+            std::string keep = g_err;
+            rt_frame_ctx_destroy_impl(fc);
+            g_err = keep;
+        }
+    } destroy{fc};
+    rc = rt_frame_ctx_set_world_impl(fc, sp, ns, tr, nt, world_index);
+    if (rc) return rc;
+    rt_frame_stats fs;
+    rc = rt_frame_ctx_render_impl(fc, rq_in, out_rgb, out_len, &fs);
+    if (rc) return rc;
+    if (stats) *stats = fs.totals;
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
 
 // ---- the exported entry points: argument-for-argument the functions above, behind guarded() ----------------------
 RT_API int rt_init(int* n_devices) { return guarded([&] { return rt_init_impl(n_devices); }); }
 RT_API void rt_shutdown(void) { (void)guarded([&] { return rt_shutdown_impl(); }); }
-RT_API int rt_scene_create(int device, const rt_sphere* sp, uint32_t ns, const rt_triangle* tr, uint32_t nt, rt_scene** out) {
-    return guarded([&] { return rt_scene_create_impl(device, sp, ns, tr, nt, out); });
+RT_API int rt_scene_create(int device, const rt_sphere* sp, uint32_t ns, const rt_triangle* tr, uint32_t nt,
+                           const uint32_t* world_index, rt_scene** out) {
+    return guarded([&] { return rt_scene_create_impl(device, sp, ns, tr, nt, world_index, out); });
 }
 RT_API void rt_scene_destroy(rt_scene* sc) { (void)guarded([&] { return rt_scene_destroy_impl(sc); }); }
 RT_API int rt_scene_render_tiles_device(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* const* d_out_rgb,
@@ -1415,13 +1744,27 @@ RT_API int rt_scene_render_tile(rt_scene* sc, const rt_tile_request* rq, uint8_t
     return guarded([&] { return rt_scene_render_tile_impl(sc, rq, out_rgb, out_len, out_f32, stats); });
 }
 RT_API int rt_render_tile(int device, const rt_tile_request* rq, const rt_sphere* sp, uint32_t ns, const rt_triangle* tr,
-                          uint32_t nt, uint8_t* out_rgb, size_t out_len, float* out_f32, rt_tile_stats* stats) {
-    return guarded([&] { return rt_render_tile_impl(device, rq, sp, ns, tr, nt, out_rgb, out_len, out_f32, stats); });
+                          uint32_t nt, const uint32_t* world_index, uint8_t* out_rgb, size_t out_len, float* out_f32,
+                          rt_tile_stats* stats) {
+    return guarded([&] { return rt_render_tile_impl(device, rq, sp, ns, tr, nt, world_index, out_rgb, out_len, out_f32, stats); });
 }
 RT_API int rt_render_frame(const int* devices, int n_devices, const rt_tile_request* rq, const rt_sphere* sp, uint32_t ns,
-                           const rt_triangle* tr, uint32_t nt, uint8_t* out_rgb, size_t out_len, rt_tile_stats* stats) {
-    return guarded([&] { return rt_render_frame_impl(devices, n_devices, rq, sp, ns, tr, nt, out_rgb, out_len, stats); });
+                           const rt_triangle* tr, uint32_t nt, const uint32_t* world_index, uint8_t* out_rgb, size_t out_len,
+                           rt_tile_stats* stats) {
+    return guarded([&] { return rt_render_frame_impl(devices, n_devices, rq, sp, ns, tr, nt, world_index, out_rgb, out_len, stats); });
 }
+RT_API int rt_frame_ctx_create(const int* devices, int n_devices, rt_frame_ctx** out) {
+    return guarded([&] { return rt_frame_ctx_create_impl(devices, n_devices, out); });
+}
+RT_API int rt_frame_ctx_set_world(rt_frame_ctx* fc, const rt_sphere* sp, uint32_t ns, const rt_triangle* tr, uint32_t nt,
+                                  const uint32_t* world_index) {
+    return guarded([&] { return rt_frame_ctx_set_world_impl(fc, sp, ns, tr, nt, world_index); });
+}
+RT_API int rt_frame_ctx_render(rt_frame_ctx* fc, const rt_tile_request* rq, uint8_t* out_rgb, size_t out_len, rt_frame_stats* stats) {
+    return guarded([&] { return rt_frame_ctx_render_impl(fc, rq, out_rgb, out_len, stats); });
+}
+RT_API int rt_frame_ctx_release_buffer(rt_frame_ctx* fc) { return guarded([&] { return rt_frame_ctx_release_buffer_impl(fc); }); }
+RT_API void rt_frame_ctx_destroy(rt_frame_ctx* fc) { (void)guarded([&] { return rt_frame_ctx_destroy_impl(fc); }); }
 // test hook (tests/test_abi.py, not part of rt_tile.h): throw inside a guarded body; the status comes back, nothing unwinds
 extern "C" __attribute__((visibility("default"))) int rt_debug_throw(int kind) {
     return guarded([&]() -> int {

@@ -104,7 +104,12 @@ inline int largest_axis(const Box& b) {             // aabb.rs:570-580
 }
 
 // Build over the primitives' AABBs (`Bounded::aabb`, sphere.rs:65-72 / mesh.rs:46-96).
-inline FlatBVH build(const std::vector<Box>& prim) {
+// `order` (optional): order[w] = the primitive at position w of the reference's `world: Vec<Object>` (lib.rs:11).  BVH::build
+// starts from `indices = 0..shapes.len()` over THAT list (bvh_impl.rs:421-427), and everything downstream keeps the list
+// order (bucket member lists, the halves of the split_at(len / 2) fallback :277-291, hence the leaves' depth-first order),
+// so the build starts from the primitives in world order; nullptr: primitive order.  Primitive numbers (boxes, leaf
+// references, leaf_of) stay those of `prim`.
+inline FlatBVH build(const std::vector<Box>& prim, const uint32_t* order = nullptr) {
     FlatBVH out;
     out.leaf_of.assign(prim.size(), 0);
     if (prim.empty()) return out;                   // the reference recurses without bound here
@@ -124,7 +129,7 @@ inline FlatBVH build(const std::vector<Box>& prim) {
     std::vector<uint8_t> bucket_of(np);
     std::vector<float> cx(np), cy(np), cz(np);          // centroids once (aabb.rs:458-484)
     for (uint32_t i = 0; i < np; i++) {
-        idx[i] = i;
+        idx[i] = order ? order[i] : i;
         float c[3];
         center(prim[i], c);
         cx[i] = c[0];

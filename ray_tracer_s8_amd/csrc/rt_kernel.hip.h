@@ -164,6 +164,8 @@ struct KParams {
     uint32_t lds_node_off;       // LDS-resident tree (ISECT 5): byte offsets of the staged nodes ...
     const float4* bvh_nodes;     // [2*n_nodes]: (lo.xyz, parent as bits) (hi.xyz, -) — rt_bvh.h FlatNode
     const uint32_t* leaf_of;     // [n_sph+n_tri] primitive -> leaf node index (= DFS rank)
+    const uint32_t* world_rank;  // [n_sph+n_tri] primitive -> position in RenderInfo.world, or nullptr (= primitive order): the
+                                 //   tie order of plain linear-scan semantics (RT_FLAG_NO_BVH_CULL)
     unsigned long long* counters;// [0] segments [1] candidates [2] fallbacks
     unsigned long long* queue;   // tile queue head of this launch (zeroed on the stream before it)
     StripDesc strips[MAX_BATCH];
@@ -1518,9 +1520,12 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
                             float t;
                             if (exact_sphere(o, td, cen, rr, p.t_min, p.t_max, t)) {
                                 WCOUNT(6);
-                                if (!use_bvh)
-                                    consider<0>(h, (int)(base + j), o, d, t, aux, p.bvh_nodes, p.leaf_of);
-                                else if (inline_chain)
+                                if (!use_bvh) {
+                                    // index order = the order of `world`: the scan runs in primitive order, so with a
+                                    // world_index an equal distance goes to the earlier world position explicitly
+                                    if (p.world_rank) consider<1>(h, (int)(base + j), o, d, t, aux, p.bvh_nodes, p.world_rank);
+                                    else consider<0>(h, (int)(base + j), o, d, t, aux, p.bvh_nodes, p.leaf_of);
+                                } else if (inline_chain)
                                     consider<2>(h, (int)(base + j), o, d, t, aux, p.bvh_nodes, p.leaf_of);
                                 else
                                     consider<1>(h, (int)(base + j), o, d, t, aux, p.bvh_nodes, p.leaf_of);
@@ -1539,9 +1544,10 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
                             continue;
                         float t;
                         if (exact_triangle(o, d, p.tri + 9 * (size_t)j, p.t_min, p.t_max, t)) {
-                            if (!use_bvh)
-                                consider<0>(h, (int)(p.n_sph + j), o, d, t, aux, p.bvh_nodes, p.leaf_of);
-                            else if (inline_chain)
+                            if (!use_bvh) {
+                                if (p.world_rank) consider<1>(h, (int)(p.n_sph + j), o, d, t, aux, p.bvh_nodes, p.world_rank);
+                                else consider<0>(h, (int)(p.n_sph + j), o, d, t, aux, p.bvh_nodes, p.leaf_of);
+                            } else if (inline_chain)
                                 consider<2>(h, (int)(p.n_sph + j), o, d, t, aux, p.bvh_nodes, p.leaf_of);
                             else
                                 consider<1>(h, (int)(p.n_sph + j), o, d, t, aux, p.bvh_nodes, p.leaf_of);

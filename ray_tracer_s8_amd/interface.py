@@ -19,7 +19,7 @@ from typing import Optional, Sequence
 import numpy as np
 
 from . import _abi
-from ._abi import TileRequest, TileStats, default_request
+from ._abi import FrameStats, TileRequest, TileStats, default_request
 from .dispatch import assemble, strips_for_worker
 
 
@@ -33,13 +33,27 @@ class RenderMeta:
 
 @dataclass
 class World:
-    """`Vec<Object>` split by variant: spheres first, then triangles (index order = tie order)."""
+    """`world: Vec<Object>` (lib.rs:11) as the C-ABI carries it: the spheres, the triangles, and `world_index` — the
+    position of every sphere, then of every triangle, in the list (None: the spheres in order, then the triangles).
+    The order is observable (BVH::build numbers shapes by position, bvh_impl.rs:421-427: leaf order, tie winners)."""
     spheres: np.ndarray = field(default_factory=lambda: np.zeros(0, _abi.SPHERE_DTYPE))
     triangles: np.ndarray = field(default_factory=lambda: np.zeros(0, _abi.TRIANGLE_DTYPE))
+    world_index: Optional[np.ndarray] = None
 
     def __post_init__(self):
         self.spheres = _abi.as_spheres(self.spheres)
         self.triangles = _abi.as_triangles(self.triangles)
+        self.world_index = _abi.as_world_index(self.world_index, len(self.spheres) + len(self.triangles))
+
+    def objects(self):
+        """The list in the reference's order: ("Sphere" | "Triangle", record) per position."""
+        n = len(self.spheres) + len(self.triangles)
+        wi = self.world_index if self.world_index is not None else np.arange(n, dtype=np.uint32)
+        out = [None] * n
+        for i in range(n):
+            out[int(wi[i])] = (("Sphere", self.spheres[i]) if i < len(self.spheres)
+                               else ("Triangle", self.triangles[i - len(self.spheres)]))
+        return out
 
 
 @dataclass
@@ -104,7 +118,8 @@ class Scene:
         self.device = device
         h = C.c_void_p()
         _abi.check(self._lib.rt_scene_create(device, _abi.ptr(world.spheres), len(world.spheres),
-                                             _abi.ptr(world.triangles), len(world.triangles), C.byref(h)),
+                                             _abi.ptr(world.triangles), len(world.triangles),
+                                             _abi.ptr(world.world_index), C.byref(h)),
                    "rt_scene_create")
         self._h = h
 
@@ -194,7 +209,8 @@ class Slave:
         # (a slave behind HTTP gets a freshly decoded world object with every strip of a job)
         w = info.world
         key = (len(w.spheres), len(w.triangles), hashlib.blake2b(w.spheres.tobytes(), digest_size=16).digest(),
-               hashlib.blake2b(w.triangles.tobytes(), digest_size=16).digest())
+               hashlib.blake2b(w.triangles.tobytes(), digest_size=16).digest(),
+               None if w.world_index is None else hashlib.blake2b(w.world_index.tobytes(), digest_size=16).digest())
         if self._scene is None or self._scene_key != key:
             if self._scene:
                 self._scene.close()
@@ -247,8 +263,67 @@ class Controller:
             s.close()
 
 
+class FrameContext:
+    """rt_frame_ctx: the controller's state for a job — dispatcher threads, the world resident on every device, streams,
+    strip buffers and the page-locked registration of the frame buffer, all made once and reused frame after frame
+    (replaces controller main.rs:47-75, 109-115)."""
+
+    def __init__(self, devices: Optional[Sequence[int]] = None, world: Optional[World] = None):
+        self._lib = _abi.load()
+        if not _initialised:
+            init()
+        if devices is None:
+            dv, nd = None, 0
+        else:
+            dv, nd = (C.c_int * len(devices))(*devices), len(devices)
+        h = C.c_void_p()
+        _abi.check(self._lib.rt_frame_ctx_create(dv, nd, C.byref(h)), "rt_frame_ctx_create")
+        self._h = h
+        self._buf = None
+        if world is not None:
+            self.set_world(world)
+
+    def set_world(self, world: World):
+        _abi.check(self._lib.rt_frame_ctx_set_world(self._h, _abi.ptr(world.spheres), len(world.spheres),
+                                                    _abi.ptr(world.triangles), len(world.triangles),
+                                                    _abi.ptr(world.world_index)), "rt_frame_ctx_set_world")
+
+    def render(self, req: TileRequest, out: Optional[np.ndarray] = None):
+        """One frame.  `out`: a uint8 array of H*W*3 bytes to write into (the SAME array frame after frame keeps its
+        page-locked registration: only the first frame pays pin_ms); default: the context's own buffer.
+        Returns (H x W x 3 view of the buffer, FrameStats)."""
+        n = req.width * req.height * 3
+        if out is None:
+            if self._buf is None or self._buf.size != n:
+                self._buf = np.empty(n, np.uint8)
+            out = self._buf
+        if out.dtype != np.uint8 or out.size < n or not out.flags.c_contiguous:
+            raise ValueError("out: need a contiguous uint8 array of at least H*W*3 bytes")
+        fs = FrameStats()
+        _abi.check(self._lib.rt_frame_ctx_render(self._h, C.byref(req), out.ctypes.data_as(C.c_void_p), out.size,
+                                                 C.byref(fs)), "rt_frame_ctx_render")
+        return out.reshape(-1)[:n].reshape(req.height, req.width, 3), fs
+
+    def release_buffer(self):
+        _abi.check(self._lib.rt_frame_ctx_release_buffer(self._h), "rt_frame_ctx_release_buffer")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.rt_frame_ctx_destroy(self._h)      # (drops the registration before the buffer can go away)
+            self._h = None
+            self._buf = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
 def render_frame_native(world: World, req: TileRequest, devices: Optional[Sequence[int]] = None):
-    """rt_render_frame: the C++ dispatcher (one host thread + stream per device)."""
+    """rt_render_frame: the one-shot form of FrameContext (create, set world, one frame, destroy)."""
     lib = _abi.load()
     if not _initialised:
         init()
@@ -260,6 +335,6 @@ def render_frame_native(world: World, req: TileRequest, devices: Optional[Sequen
     else:
         dv, nd = (C.c_int * len(devices))(*devices), len(devices)
     _abi.check(lib.rt_render_frame(dv, nd, C.byref(req), _abi.ptr(world.spheres), len(world.spheres),
-                                   _abi.ptr(world.triangles), len(world.triangles),
+                                   _abi.ptr(world.triangles), len(world.triangles), _abi.ptr(world.world_index),
                                    out.ctypes.data_as(C.c_void_p), n, C.byref(st)), "rt_render_frame")
     return out.reshape(req.height, req.width, 3), st

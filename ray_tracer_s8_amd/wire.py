@@ -10,8 +10,9 @@ mesh.rs:14-23, color.rs:5-10):
 f32 values travel as the shortest decimal of the f32 widened to f64 (serde_json `Value::from(f32)`), so the
 round trip is exact; that is what `float(np.float32(x))` + Python's repr produce as well.
 
-The reference `world` is one ordered list mixing both variants; the GPU ABI takes spheres then
-triangles, so decoding splits the list and keeps each variant's relative order.
+The reference `world` is one ordered list mixing both variants; the GPU ABI takes two typed arrays plus
+`world_index`, the position of every primitive in that list (include/rt_tile.h "the world's order"), so decoding splits
+the list and records where each entry stood, and encoding writes the entries back at their positions.
 """
 from __future__ import annotations
 
@@ -46,12 +47,12 @@ def triangle_to_obj(t) -> dict:
 
 
 def world_to_json_obj(world: World) -> list:
-    return [sphere_to_obj(s) for s in world.spheres] + [triangle_to_obj(t) for t in world.triangles]
+    return [sphere_to_obj(rec) if tag == "Sphere" else triangle_to_obj(rec) for tag, rec in world.objects()]
 
 
 def world_from_json_obj(objs: list) -> World:
-    sph, tri = [], []
-    for o in objs:
+    sph, tri, pos_s, pos_t = [], [], [], []
+    for pos, o in enumerate(objs):
         if not isinstance(o, dict) or len(o) != 1:
             raise ValueError("Object must be an externally tagged enum: {\"Sphere\":{..}} or {\"Triangle\":{..}}")
         (tag, v), = o.items()
@@ -60,18 +61,26 @@ def world_from_json_obj(objs: list) -> World:
             c = v["center"]
             sph.append((c[0], c[1], c[2], v["radius"], col["r"], col["g"], col["b"], v["p_roughness_at"],
                         v["p_emission_at"]))
+            pos_s.append(pos)
         elif tag == "Triangle":
             tri.append((tuple(v["a"]), tuple(v["b"]), tuple(v["c"]), col["r"], col["g"], col["b"],
                         v["p_roughness_at"], v["p_emission_at"]))
+            pos_t.append(pos)
         else:
             raise ValueError(f"unknown variant `{tag}`, expected `Sphere` or `Triangle`")
+    # world_index only when the list is NOT already "spheres, then triangles" (None means exactly that order)
+    wi = np.array(pos_s + pos_t, dtype=np.uint32)
+    interleaved = bool(len(wi)) and not np.array_equal(wi, np.arange(len(wi), dtype=np.uint32))
     return World(np.array(sph, dtype=SPHERE_DTYPE) if sph else np.zeros(0, SPHERE_DTYPE),
-                 np.array(tri, dtype=TRIANGLE_DTYPE) if tri else np.zeros(0, TRIANGLE_DTYPE))
+                 np.array(tri, dtype=TRIANGLE_DTYPE) if tri else np.zeros(0, TRIANGLE_DTYPE),
+                 wi if interleaved else None)
 
 
 def world_to_json_text(world: World) -> str:
     """The `world` array as compact JSON text, the same text json.dumps(world_to_json_obj(world)) gives (floats as the
     shortest repr of the f32 value widened to f64), assembled with one format call per primitive."""
+    if world.world_index is not None:
+        return json.dumps(world_to_json_obj(world), separators=(",", ":"))
     parts = []
     if len(world.spheres):
         s = world.spheres

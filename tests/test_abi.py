@@ -22,7 +22,8 @@ def test_header_declares_expected_surface():
     for must in ("rt_init", "rt_shutdown", "rt_strerror", "rt_last_error", "rt_render_tile", "rt_scene_create",
                  "rt_scene_destroy", "rt_scene_render_tile", "rt_scene_render_tile_device",
                  "rt_scene_render_tiles_device", "rt_scene_render_tiles", "rt_scene_collect", "rt_render_frame",
-                 "rt_tile_request_defaults", "rt_tile_bytes", "rt_abi_version"):
+                 "rt_frame_ctx_create", "rt_frame_ctx_set_world", "rt_frame_ctx_render", "rt_frame_ctx_release_buffer",
+                 "rt_frame_ctx_destroy", "rt_tile_request_defaults", "rt_tile_bytes", "rt_abi_version"):
         assert must in names, must
 
 
@@ -30,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     lib = _abi.load()
     for name in declared_functions():
         assert hasattr(lib, name), f"{name} declared in rt_tile.h but not exported by librt_s8.so"
-    assert lib.rt_abi_version() == 2 == _abi.RT_ABI_VERSION
+    assert lib.rt_abi_version() == 3 == _abi.RT_ABI_VERSION
 
 
 def test_abi_version_is_one_number_everywhere():
@@ -52,6 +53,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_abi.TileRequest) == 64
     assert _abi.SPHERE_DTYPE.itemsize == 36 and _abi.TRIANGLE_DTYPE.itemsize == 56
     assert C.sizeof(_abi.TileStats) == 64
+    assert C.sizeof(_abi.FrameStats) == 96 and _abi.FrameStats.wall_ms.offset == 64 and _abi.FrameStats.pinned.offset == 92
     offs = {n: getattr(_abi.TileRequest, n).offset for n, _ in _abi.TileRequest._fields_}
     assert offs["width"] == 0 and offs["spp"] == 16 and offs["aperture"] == 24 and offs["seed"] == 48 and offs["flags"] == 56
 
@@ -90,14 +92,16 @@ def test_fails_loudly_without_device_or_init():
     assert "hipGetDeviceCount" in lib.rt_last_error().decode()
     sph = np.zeros(1, _abi.SPHERE_DTYPE)
     h = C.c_void_p()
-    assert lib.rt_scene_create(0, _abi.ptr(sph), 1, None, 0, C.byref(h)) == _abi.RT_ERR_NOT_INITIALIZED
+    assert lib.rt_scene_create(0, _abi.ptr(sph), 1, None, 0, None, C.byref(h)) == _abi.RT_ERR_NOT_INITIALIZED
     rq = _abi.default_request(width=8, height=8, divisions=1, spp=1)
     out = np.zeros(8 * 8 * 3, np.uint8)
     st = _abi.TileStats()
-    assert lib.rt_render_tile(0, C.byref(rq), _abi.ptr(sph), 1, None, 0, _abi.ptr(out), out.size, None,
+    assert lib.rt_render_tile(0, C.byref(rq), _abi.ptr(sph), 1, None, 0, None, _abi.ptr(out), out.size, None,
                               C.byref(st)) == _abi.RT_ERR_NOT_INITIALIZED
-    assert lib.rt_render_frame(None, 0, C.byref(rq), _abi.ptr(sph), 1, None, 0, _abi.ptr(out), out.size,
+    assert lib.rt_render_frame(None, 0, C.byref(rq), _abi.ptr(sph), 1, None, 0, None, _abi.ptr(out), out.size,
                                C.byref(st)) == _abi.RT_ERR_NOT_INITIALIZED
+    fc = C.c_void_p()
+    assert lib.rt_frame_ctx_create(None, 0, C.byref(fc)) == _abi.RT_ERR_NOT_INITIALIZED and not fc.value
 
 
 def test_argument_checks_before_any_device_work():
@@ -106,7 +110,7 @@ def test_argument_checks_before_any_device_work():
     out = np.zeros(64, np.uint8)
     st = _abi.TileStats()
     rq = _abi.default_request(width=8, height=8, divisions=1, spp=1)
-    call = lambda r, o=out, n=None: lib.rt_render_tile(0, C.byref(r), _abi.ptr(sph), 1, None, 0, _abi.ptr(o),
+    call = lambda r, o=out, n=None: lib.rt_render_tile(0, C.byref(r), _abi.ptr(sph), 1, None, 0, None, _abi.ptr(o),
                                                        o.size if n is None else n, None, C.byref(st))
     bad = rq.copy(); bad.division_no = 1
     assert call(bad) == _abi.RT_ERR_BAD_ARG
@@ -117,7 +121,7 @@ def test_argument_checks_before_any_device_work():
     bad = rq.copy(); bad.reserved = 1
     assert call(bad) == _abi.RT_ERR_BAD_ARG
     assert call(rq) == _abi.RT_ERR_BUFFER_TOO_SMALL                   # 64 < 8*8*3
-    assert lib.rt_render_tile(0, None, None, 0, None, 0, None, 0, None, None) == _abi.RT_ERR_BAD_ARG
+    assert lib.rt_render_tile(0, None, None, 0, None, 0, None, None, 0, None, None) == _abi.RT_ERR_BAD_ARG
     assert lib.rt_tile_bytes(None) == 0
 
 
@@ -174,10 +178,85 @@ def test_scene_size_limit_is_checked_before_anything_is_allocated():
     sph = np.zeros(1, _abi.SPHERE_DTYPE)
     out = C.c_void_p()
     too_many = 0x3ffffff + 1
-    rc = lib.rt_scene_create(0, sph.ctypes.data_as(C.c_void_p), C.c_uint32(too_many), None, C.c_uint32(0), C.byref(out))
+    rc = lib.rt_scene_create(0, sph.ctypes.data_as(C.c_void_p), C.c_uint32(too_many), None, C.c_uint32(0), None, C.byref(out))
     assert rc == -8 and not out.value
     rq = _abi.default_request(width=8, height=8, divisions=1, spp=1)
     buf = np.zeros(8 * 8 * 3, np.uint8)
     rc = lib.rt_render_frame(None, 0, C.byref(rq), sph.ctypes.data_as(C.c_void_p), C.c_uint32(too_many), None, C.c_uint32(0),
-                             buf.ctypes.data_as(C.c_void_p), C.c_size_t(buf.size), None)
+                             None, buf.ctypes.data_as(C.c_void_p), C.c_size_t(buf.size), None)
     assert rc == -8
+
+
+def test_world_index_must_be_a_permutation():
+    """world_index (rt_tile.h "the world's order") is checked before any device work: out of range, repeated."""
+    lib = _abi.load()
+    sph = np.zeros(2, _abi.SPHERE_DTYPE)
+    tri = np.zeros(1, _abi.TRIANGLE_DTYPE)
+    h = C.c_void_p()
+    for bad in ([0, 1, 3], [0, 0, 1], [2, 2, 2]):
+        wi = np.array(bad, np.uint32)
+        assert lib.rt_scene_create(0, _abi.ptr(sph), 2, _abi.ptr(tri), 1, _abi.ptr(wi), C.byref(h)) == _abi.RT_ERR_BAD_ARG
+        assert b"permutation" in lib.rt_last_error() and not h.value
+    rq = _abi.default_request(width=8, height=8, divisions=1, spp=1)
+    buf = np.zeros(8 * 8 * 3, np.uint8)
+    wi = np.array([5, 0, 1], np.uint32)
+    assert lib.rt_render_frame(None, 0, C.byref(rq), _abi.ptr(sph), 2, _abi.ptr(tri), 1, _abi.ptr(wi), _abi.ptr(buf),
+                               buf.size, None) == _abi.RT_ERR_BAD_ARG
+    assert lib.rt_render_tile(0, C.byref(rq), _abi.ptr(sph), 2, _abi.ptr(tri), 1, _abi.ptr(wi), _abi.ptr(buf), buf.size,
+                              None, None) == _abi.RT_ERR_BAD_ARG
+    with pytest.raises(ValueError):
+        from ray_tracer_s8_amd.interface import World
+        World(sph, tri, world_index=[0, 1])                      # one entry per primitive
+
+
+def test_frame_context_lifecycle_and_error_paths():
+    """rt_frame_ctx_*: argument errors come back as statuses (nothing dereferenced, nothing thrown), destroy(NULL) is a
+    no-op; on a GPU box: create / destroy without a world, render before set_world, bad devices, frame-size errors."""
+    lib = _abi.load()
+    st = _abi.FrameStats()
+    rq = _abi.default_request(width=8, height=8, divisions=1, spp=1)
+    buf = np.zeros(8 * 8 * 3, np.uint8)
+    sph = np.zeros(1, _abi.SPHERE_DTYPE)
+    assert lib.rt_frame_ctx_create(None, 0, None) == _abi.RT_ERR_BAD_ARG
+    assert lib.rt_frame_ctx_set_world(None, _abi.ptr(sph), 1, None, 0, None) == _abi.RT_ERR_BAD_ARG
+    assert lib.rt_frame_ctx_render(None, C.byref(rq), _abi.ptr(buf), buf.size, C.byref(st)) == _abi.RT_ERR_BAD_ARG
+    assert lib.rt_frame_ctx_release_buffer(None) == _abi.RT_ERR_BAD_ARG
+    lib.rt_frame_ctx_destroy(None)
+    n = C.c_int(0)
+    if lib.rt_init(C.byref(n)) != _abi.RT_OK:                    # CPU container: no context can exist
+        fc = C.c_void_p()
+        assert lib.rt_frame_ctx_create(None, 0, C.byref(fc)) == _abi.RT_ERR_NOT_INITIALIZED
+        return
+    fc = C.c_void_p()
+    bad_dev = (C.c_int * 1)(99)
+    assert lib.rt_frame_ctx_create(bad_dev, 1, C.byref(fc)) == _abi.RT_ERR_BAD_DEVICE and not fc.value
+    dev0 = (C.c_int * 2)(0, 0)
+    assert lib.rt_frame_ctx_create(dev0, 2, C.byref(fc)) == _abi.RT_OK and fc.value
+    assert lib.rt_frame_ctx_render(fc, C.byref(rq), _abi.ptr(buf), buf.size, C.byref(st)) == _abi.RT_ERR_BAD_ARG
+    assert b"set_world" in lib.rt_last_error()
+    assert lib.rt_frame_ctx_set_world(fc, None, 1, None, 0, None) == _abi.RT_ERR_BAD_ARG        # count without a pointer
+    assert lib.rt_frame_ctx_set_world(fc, _abi.ptr(sph), 1, None, 0, None) == _abi.RT_OK
+    assert lib.rt_frame_ctx_render(fc, None, _abi.ptr(buf), buf.size, None) == _abi.RT_ERR_BAD_ARG
+    assert lib.rt_frame_ctx_render(fc, C.byref(rq), None, buf.size, None) == _abi.RT_ERR_BAD_ARG
+    assert lib.rt_frame_ctx_render(fc, C.byref(rq), _abi.ptr(buf), 10, None) == _abi.RT_ERR_BUFFER_TOO_SMALL
+    odd = rq.copy(); odd.divisions = 3
+    assert lib.rt_frame_ctx_render(fc, C.byref(odd), _abi.ptr(buf), buf.size, None) == _abi.RT_ERR_FRAME_SIZE
+    assert lib.rt_frame_ctx_render(fc, C.byref(rq), _abi.ptr(buf), buf.size, C.byref(st)) == _abi.RT_OK
+    assert st.n_devices == 2 and st.totals.primary_rays == 64 and st.wall_ms > 0
+    assert lib.rt_frame_ctx_release_buffer(fc) == _abi.RT_OK
+    lib.rt_frame_ctx_destroy(fc)
+
+
+def test_library_records_its_compile_flags(monkeypatch):
+    """An A/B script that dies before restoring the default build must not leave a variant that looks fresh (round-2
+    advisor): the compile lines are stored next to the library, a library built with other flags than the ones asked for
+    now is stale whatever its mtime, and the driver's build check insists on the default flags."""
+    from ray_tracer_s8_amd import build
+    _abi.load()
+    monkeypatch.delenv("RT_EXTRA_HIPCC_FLAGS", raising=False)
+    assert build.built_with_default_flags() and not build.needs_build()
+    monkeypatch.setenv("RT_EXTRA_HIPCC_FLAGS", "-DRT_PROFILE_TIME")
+    assert build.needs_build()                                     # a variant is asked for: the default library is stale for it
+    assert build.flags_record() != build.flags_record([]) and "-DRT_PROFILE_TIME" in build.flags_record()
+    entry = (ROOT / "__graft_entry__.py").read_text()
+    assert "built_with_default_flags()" in entry

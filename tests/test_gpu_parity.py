@@ -258,14 +258,14 @@ def test_error_paths(ndev):
     out = np.zeros(64 * 64 * 3, np.uint8)
     st = _abi.TileStats()
     bad = rq.copy(); bad.division_no = 1
-    assert lib.rt_render_tile(0, C.byref(bad), _abi.ptr(sph), 1, None, 0, _abi.ptr(out), out.size, None, C.byref(st)) == _abi.RT_ERR_BAD_ARG
-    assert lib.rt_render_tile(0, C.byref(rq), _abi.ptr(sph), 1, None, 0, _abi.ptr(out), 10, None, C.byref(st)) == _abi.RT_ERR_BUFFER_TOO_SMALL
-    assert lib.rt_render_tile(99, C.byref(rq), _abi.ptr(sph), 1, None, 0, _abi.ptr(out), out.size, None, C.byref(st)) == _abi.RT_ERR_BAD_DEVICE
+    assert lib.rt_render_tile(0, C.byref(bad), _abi.ptr(sph), 1, None, 0, None, _abi.ptr(out), out.size, None, C.byref(st)) == _abi.RT_ERR_BAD_ARG
+    assert lib.rt_render_tile(0, C.byref(rq), _abi.ptr(sph), 1, None, 0, None, _abi.ptr(out), 10, None, C.byref(st)) == _abi.RT_ERR_BUFFER_TOO_SMALL
+    assert lib.rt_render_tile(99, C.byref(rq), _abi.ptr(sph), 1, None, 0, None, _abi.ptr(out), out.size, None, C.byref(st)) == _abi.RT_ERR_BAD_DEVICE
     bad = rq.copy(); bad.max_bounces = 1000
-    assert lib.rt_render_tile(0, C.byref(bad), _abi.ptr(sph), 1, None, 0, _abi.ptr(out), out.size, None, C.byref(st)) == _abi.RT_ERR_LIMIT
+    assert lib.rt_render_tile(0, C.byref(bad), _abi.ptr(sph), 1, None, 0, None, _abi.ptr(out), out.size, None, C.byref(st)) == _abi.RT_ERR_LIMIT
     fr = rq.copy(); fr.height = 65; fr.divisions = 2
     big = np.zeros(65 * 64 * 3, np.uint8)
-    assert lib.rt_render_frame(None, 0, C.byref(fr), _abi.ptr(sph), 1, None, 0, _abi.ptr(big), big.size, C.byref(st)) == _abi.RT_ERR_FRAME_SIZE
+    assert lib.rt_render_frame(None, 0, C.byref(fr), _abi.ptr(sph), 1, None, 0, None, _abi.ptr(big), big.size, C.byref(st)) == _abi.RT_ERR_FRAME_SIZE
     assert lib.rt_last_error().decode() != ""
 
 
@@ -426,9 +426,9 @@ def test_two_host_threads_on_one_device(ndev):
     assert st_a.n_launches == 2 and st_b.n_launches == 2     # [0]: six strips = five + the last under their D2H
 
 
-def test_frame_dispatcher_strip_queue_and_pinning(ndev, oracle, monkeypatch):
+def test_frame_dispatcher_strip_queue_and_pinning(ndev, oracle):
     """rt_render_frame's assignments give the same frame: static strip k -> device k mod n in one batch (default),
-    and RT_FRAME_QUEUE=1 — strips pulled bottom-up from a host-atomic queue, two launches in flight per device —
+    and RT_FLAG_FRAME_QUEUE — strips pulled bottom-up from a host-atomic queue, two launches in flight per device —
     with one and with three dispatcher threads on GPU 0, with and without the page-locked frame buffer."""
     sph, rq = _small("c3", 256, 144, spp=3, div=12)
     ref, st_ref = rt.render_frame_native(rt.World(sph), rq, devices=[0])
@@ -436,27 +436,75 @@ def test_frame_dispatcher_strip_queue_and_pinning(ndev, oracle, monkeypatch):
     one.divisions = 1
     want, _, info = oracle.render(one, sph, backend=1)
     assert np.array_equal(ref.reshape(-1), want)
-    for env in ({"RT_FRAME_QUEUE": "1"}, {"RT_FRAME_QUEUE": "1", "RT_PIN_FRAME": "0"}, {"RT_PIN_FRAME": "0"}):
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
+    Q, NP = _abi.RT_FLAG_FRAME_QUEUE, _abi.RT_FLAG_FRAME_NO_PIN
+    for fl in (Q, Q | NP, NP):
+        r = rq.copy()
+        r.flags = fl
         for devs in ([0], [0, 0, 0]):
-            img, st = rt.render_frame_native(rt.World(sph), rq, devices=devs)
-            assert np.array_equal(img, ref), (env, devs)
+            img, st = rt.render_frame_native(rt.World(sph), r, devices=devs)
+            assert np.array_equal(img, ref), (fl, devs)
             assert st.ray_segments == st_ref.ray_segments == info["ray_segments"]
-            if "RT_FRAME_QUEUE" in env:
+            if fl & Q:
                 assert st.n_launches == 12                   # one launch per strip
-        for k in env:
-            monkeypatch.delenv(k)
+
+
+def test_frame_context_reuses_everything_across_frames(ndev, oracle):
+    """rt_frame_ctx: the job's state is made once.  Frame 1 pays the page-locking and carries the world's preparation in
+    scene_ms; frames 2.. of the job (same world, same buffer) register, upload and spawn nothing: pin_ms == scene_ms == 0,
+    the buffer stays page-locked.  Static and strip-queue frames, seeds, a second world and a second buffer in one
+    context; every frame equals the oracle's."""
+    sph, rq = _small("c3", 256, 144, spp=3, div=12)
+    one = rq.copy()
+    one.divisions = 1
+    buf = np.zeros(256 * 144 * 3, np.uint8)
+    with rt.FrameContext(devices=[0, 0], world=rt.World(sph)) as fc:
+        img, fs = fc.render(rq, out=buf)
+        want, _, info = oracle.render(one, sph, backend=1)
+        assert np.array_equal(img.reshape(-1), want) and fs.totals.ray_segments == info["ray_segments"]
+        assert fs.scene_ms > 0 and fs.pinned == 1 and fs.pin_ms > 0 and fs.n_devices == 2
+        assert abs(fs.wall_ms - (fs.pin_ms + fs.kernel_ms + fs.d2h_exposed_ms + fs.host_ms)) < 1e-3
+        for seed, fl in ((1, 0), (2, _abi.RT_FLAG_FRAME_QUEUE), (3, 0)):
+            r = rq.copy()
+            r.seed, r.flags = seed, fl
+            img, fs = fc.render(r, out=buf)
+            o = one.copy()
+            o.seed = seed
+            want, _, _ = oracle.render(o, sph, backend=1)
+            assert np.array_equal(img.reshape(-1), want), (seed, fl)
+            assert fs.pin_ms == 0.0 and fs.scene_ms == 0.0 and fs.pinned == 1
+        # another buffer: registered in its turn (the first is released); NO_PIN: nothing registered
+        img2, fs2 = fc.render(rq)
+        assert fs2.pin_ms > 0 and fs2.pinned == 1 and np.array_equal(img2.reshape(-1), oracle.render(one, sph, backend=1)[0])
+        img2 = img2.copy()
+        r = rq.copy()
+        r.flags = _abi.RT_FLAG_FRAME_NO_PIN
+        img3, fs3 = fc.render(r, out=buf)
+        assert fs3.pinned == 0 and fs3.pin_ms == 0.0 and np.array_equal(img3, img2)
+        # a second world in the same context
+        sph2 = scenes.cornell16()
+        fc.set_world(rt.World(sph2))
+        img4, fs4 = fc.render(rq, out=buf)
+        want4, _, _ = oracle.render(one, sph2, backend=1)
+        assert np.array_equal(img4.reshape(-1), want4) and fs4.scene_ms > 0
+        fc.release_buffer()
 
 
 @pytest.mark.parametrize("cull", [0, _abi.RT_FLAG_CULL_WALK])
-def test_capped_stack_launches_on_two_streams(ndev, oracle, monkeypatch, cull):
+def test_capped_stack_launches_on_two_streams(ndev, oracle, cull):
     """The capped-stack walk (stack entries beyond a few LDS slots live in one per-scene HBM area) enqueued on two
     streams at once: the library chains such launches, so frames rendered 'concurrently' are still exact.  Both the plain
     and the culled walk have a capped-stack variant."""
     hip = C.CDLL("libamdhip64.so")
-    monkeypatch.setenv("RT_FORCE_CAPPED", "1")
-    monkeypatch.setenv("RT_STACK_LDS", "3")
+    rt.init()
+    prev = [_abi.debug_set("RT_FORCE_CAPPED", 1), _abi.debug_set("RT_STACK_LDS", 3)]
+    try:
+        _capped_two_streams(hip, oracle, cull)
+    finally:
+        _abi.debug_set("RT_FORCE_CAPPED", prev[0])
+        _abi.debug_set("RT_STACK_LDS", prev[1])
+
+
+def _capped_two_streams(hip, oracle, cull):
     sph = scenes.rand65536(n=9000)
     rq = _abi.default_request(width=128, height=80, divisions=1, spp=2, max_bounces=5, seed=99,
                               flags=_abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_QUANT_NODES | cull)
@@ -493,18 +541,25 @@ def test_capped_stack_launches_on_two_streams(ndev, oracle, monkeypatch, cull):
         assert np.array_equal(h, want)
 
 
-def test_frame_over_two_devices(ndev, oracle, monkeypatch):
-    """rt_render_frame over devices [0, 1] (and the strip queue over them): the same frame as one device.  Needs a box with
-    two GPUs; the one-GPU boxes of rounds 1-2 skip it."""
+def test_frame_over_two_devices(ndev, oracle):
+    """rt_render_frame and a persistent rt_frame_ctx over devices [0, 1] (and the strip queue over them): the same frame as
+    one device, frame after frame.  Needs a box with two GPUs; the one-GPU boxes of rounds 1-3 skip it."""
     if ndev < 2:
         pytest.skip("needs two GPUs")
     sph, rq = _small("c3", 256, 144, spp=3, div=12)
     ref, st_ref = rt.render_frame_native(rt.World(sph), rq, devices=[0])
     img, st = rt.render_frame_native(rt.World(sph), rq, devices=[0, 1])
     assert np.array_equal(img, ref) and st.ray_segments == st_ref.ray_segments
-    monkeypatch.setenv("RT_FRAME_QUEUE", "1")
-    img, st = rt.render_frame_native(rt.World(sph), rq, devices=[1, 0])
+    q = rq.copy()
+    q.flags = _abi.RT_FLAG_FRAME_QUEUE
+    img, st = rt.render_frame_native(rt.World(sph), q, devices=[1, 0])
     assert np.array_equal(img, ref) and st.ray_segments == st_ref.ray_segments
+    with rt.FrameContext(devices=[1, 0], world=rt.World(sph)) as fc:     # (device 0 is not the first entry: the
+        buf = np.zeros(256 * 144 * 3, np.uint8)                          #  registration must not assume it)
+        for r in (rq, q, rq):
+            img, fs = fc.render(r, out=buf)
+            assert np.array_equal(img, ref) and fs.totals.ray_segments == st_ref.ray_segments and fs.n_devices == 2
+        assert fs.pin_ms == 0.0 and fs.scene_ms == 0.0
 
 
 def test_shutdown_is_refused_while_a_scene_is_alive(ndev):
