@@ -207,3 +207,9 @@ def axis_get(v, axis: int) -> float:
 def ray_intersects_aabb(origin, direction, box6) -> bool:
     return bool(load().rt_oracle_ray_intersects_aabb(_p(_f3(origin)), _p(_f3(direction)),
                                                      _p(np.ascontiguousarray(box6, np.float32))))
+
+
+def ray_intersects_aabb_flipped(origin, direction, box6) -> bool:
+    """Ray::new(origin, direction), then direction and inv_direction negated with the cached signs kept (B/ray.rs:420-423)."""
+    return bool(load().rt_oracle_ray_intersects_aabb_flipped(_p(_f3(origin)), _p(_f3(direction)),
+                                                             _p(np.ascontiguousarray(box6, np.float32))))

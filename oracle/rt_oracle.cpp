@@ -970,6 +970,15 @@ __attribute__((visibility("default"))) int rt_oracle_ray_intersects_aabb(const f
     const Ray r = ray_new(arr3(origin), arr3(dir));
     return intersects_aabb(r, AABB{v3(box6[0], box6[1], box6[2]), v3(box6[3], box6[4], box6[5])}) ? 1 : 0;
 }
+// The same with the ray turned round the way the crate's own property tests do it (B/ray.rs:420-423):
+// `ray.direction = -ray.direction; ray.inv_direction = -ray.inv_direction;` — the cached signs are NOT refreshed.
+__attribute__((visibility("default"))) int rt_oracle_ray_intersects_aabb_flipped(const float* origin, const float* dir,
+                                                                                 const float* box6) {
+    Ray r = ray_new(arr3(origin), arr3(dir));
+    r.direction = v3(-r.direction.x, -r.direction.y, -r.direction.z);
+    r.inv_direction = v3(-r.inv_direction.x, -r.inv_direction.y, -r.inv_direction.z);
+    return intersects_aabb(r, AABB{v3(box6[0], box6[1], box6[2]), v3(box6[3], box6[4], box6[5])}) ? 1 : 0;
+}
 // BVH over raw AABBs (n boxes, 6 floats each: min xyz, max xyz); traverse one ray; returns
 // number of candidate shape indices written to out_idx (DFS leaf order), capacity cap.
 __attribute__((visibility("default"))) int rt_oracle_bvh_traverse_boxes(const float* boxes, uint32_t n,

@@ -42,10 +42,11 @@ std::vector<rtbvh::Box> to_boxes(const float* b, uint32_t n) {
 
 extern "C" {
 
-// candidates of one ray in the product tree, depth-first order; returns their number, *n_nodes = nodes built
-int host_bvh_traverse(const float* boxes, uint32_t n, const float* origin, const float* dir, uint32_t* out,
-                      uint32_t cap, uint32_t* n_nodes, uint32_t* depth) {
-    const rtbvh::FlatBVH t = rtbvh::build(to_boxes(boxes, n));
+// candidates of one ray in the product tree, depth-first order; returns their number, *n_nodes = nodes built.
+// order (may be NULL): order[w] = the primitive at position w of the reference's `world` list (rt_bvh.h build()).
+int host_bvh_traverse_ordered(const float* boxes, uint32_t n, const uint32_t* order, const float* origin, const float* dir,
+                              uint32_t* out, uint32_t cap, uint32_t* n_nodes, uint32_t* depth) {
+    const rtbvh::FlatBVH t = rtbvh::build(to_boxes(boxes, n), order);
     if (n_nodes) *n_nodes = (uint32_t)t.nodes.size();
     if (depth) *depth = t.depth;
     if (n == 0) return 0;
@@ -84,6 +85,11 @@ int host_bvh_traverse(const float* boxes, uint32_t n, const float* origin, const
     }
     for (uint32_t i = 0; i < c.size() && i < cap; i++) out[i] = c[i];
     return (int)c.size();
+}
+
+int host_bvh_traverse(const float* boxes, uint32_t n, const float* origin, const float* dir, uint32_t* out,
+                      uint32_t cap, uint32_t* n_nodes, uint32_t* depth) {
+    return host_bvh_traverse_ordered(boxes, n, nullptr, origin, dir, out, cap, n_nodes, depth);
 }
 
 // Structure checks of the flat tree and its quantised twin.  Returns 0 when every check holds, else a code:
@@ -204,6 +210,20 @@ int host_ray_hits_box(const float* origin, const float* dir, const float* box6) 
         const float d = dir[a] / len;
         r.o[a] = origin[a];
         r.inv[a] = 1.0f / d;
+        r.s[a] = d < 0.0f;
+    }
+    return hits(r, box6, box6 + 3) ? 1 : 0;
+}
+
+// the same ray turned round as the crate's property tests do (ray.rs:420-423): direction and inverse direction negated,
+// the cached signs kept
+int host_ray_hits_box_flipped(const float* origin, const float* dir, const float* box6) {
+    const float len = sqrtf((dir[0] * dir[0] + dir[1] * dir[1]) + dir[2] * dir[2]);
+    HRay r;
+    for (int a = 0; a < 3; a++) {
+        const float d = dir[a] / len;
+        r.o[a] = origin[a];
+        r.inv[a] = -(1.0f / d);
         r.s[a] = d < 0.0f;
     }
     return hits(r, box6, box6 + 3) ? 1 : 0;
