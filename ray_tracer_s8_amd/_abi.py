@@ -221,6 +221,45 @@ def as_world_index(a, n: int):
     return a
 
 
+def hip_runtime_path() -> str:
+    """The libamdhip64 file the library's HIP calls are bound to (rt_debug_hip_runtime).  PyTorch wheels bundle their own
+    runtime; whichever of torch / this library is loaded FIRST decides which one this library uses
+    (profiles/README.md, "two HIP runtimes in one process")."""
+    lib = load()
+    lib.rt_debug_hip_runtime.argtypes = [C.c_char_p, C.c_size_t]
+    lib.rt_debug_hip_runtime.restype = C.c_size_t
+    buf = C.create_string_buffer(4096)
+    return buf.value.decode() if lib.rt_debug_hip_runtime(buf, 4096) else ""
+
+
+def hip_runtime() -> C.CDLL:
+    """ctypes handle of THAT runtime (already mapped: the same instance the library uses), for callers that make their own
+    streams or device buffers (tests)."""
+    p = hip_runtime_path()
+    if not p:
+        raise RuntimeError("cannot tell which HIP runtime librt_s8.so is bound to")
+    return C.CDLL(p)
+
+
+def check_single_hip_runtime() -> None:
+    """Refuse a process in which torch and this library would drive the GPU through DIFFERENT HIP runtimes: the second one
+    to initialise finds "no ROCm-capable device" (round 2: torch.cuda.Stream() after 122 tests of this library), and a stream
+    or event made by one is garbage to the other.  Safe orders: import torch first (the library then binds to torch's
+    runtime), or never import torch in the process."""
+    import sys
+    if "torch" not in sys.modules:
+        return
+    import os
+    torch = sys.modules["torch"]
+    tdir = os.path.realpath(os.path.join(os.path.dirname(torch.__file__), "lib"))
+    mine = os.path.realpath(hip_runtime_path())
+    bundled = os.path.exists(os.path.join(tdir, "libamdhip64.so"))
+    if bundled and mine and os.path.dirname(mine) != tdir:
+        raise RuntimeError(f"librt_s8.so is bound to {mine} but torch brings its own HIP runtime in {tdir}: two HIP runtimes in one "
+                           "process cannot share the device.  Import torch BEFORE loading ray_tracer_s8_amd, or keep torch out "
+                           "of this process.")
+
+
 def debug_set(name: str, value: int) -> int:
     """Set a launch-path knob (RT_FORCE_CAPPED, RT_STACK_LDS, RT_CULL_WALK, ...: csrc/rt_api.hip DebugKnob); returns the
     previous value.  Tests and tools only."""

@@ -43,7 +43,7 @@ UNITS = [
 
 
 def _deps() -> list[Path]:
-    return [CSRC / u for u, _ in UNITS] + [CSRC / "rt_kernel.hip.h", CSRC / "rt_bvh.h", ROOT / "include" / "rt_tile.h",
+    return [CSRC / u for u, _ in UNITS] + [CSRC / "rt_kernel.hip.h", CSRC / "rt_cull.h", CSRC / "rt_bvh.h", ROOT / "include" / "rt_tile.h",
                                             Path(__file__)]
 
 

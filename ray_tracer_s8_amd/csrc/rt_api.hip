@@ -5,6 +5,7 @@
 // controller's dispatch + assembly (ray-tracer-controller/src/main.rs:47-75, 109-115).
 // No torch types, no CPU fallback: without a HIP device every entry point fails loudly.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <chrono>
@@ -904,7 +905,11 @@ static void build_host_scene(const rt_sphere* sp, uint32_t ns, const rt_triangle
         const double root = ex * ey + ey * ez + ez * ex, diag = std::sqrt(ex * ex + ey * ey + ez * ez);
         hs.cull_density = root > 0.0 ? (float)(area / root) : 0.f;
         hs.cull_pays = nt == 0 && root > 0.0 && std::isfinite(area / root) && area / root >= 0.7 && (double)rs <= 0.05 * diag;
-        // Scenes with triangles (culled walk over the EXACT nodes, cull_bound_tri in rt_kernel.hip.h): its bound needs every
+        // (What the bounds claim — no accepted root of a primitive outside the `big` list enters its box beyond cull_bound /
+        // cull_bound_tri of its compared distance — is tested by itself, on 1.8e7 seeded and adversarial (ray, primitive, box)
+        // triples incl. K -> 0.25, |det| -> 1e-5, origins at 1e3 and tangent rays: tests/test_cull_lemma.py with the bounds
+        // of csrc/rt_cull.h; reduced soaks against the oracle: tests/test_gpu_cull_soaks.py.)
+        // Scenes with triangles (culled walk over the EXACT nodes, cull_bound_tri in rt_cull.h): its bound needs every
         // triangle outside the `big` list to have K = |e1||e2| <= 0.25 (with the reference's |det| >= 1e-5 that keeps the
         // computed determinant within 1.5 % of the true one) and carries the largest box diagonal as slack, so triangles with
         // a larger K, or a box diagonal of more than 8 x the median, join the list (16 entries with the spheres; more: no culling).
@@ -1765,6 +1770,23 @@ RT_API int rt_frame_ctx_render(rt_frame_ctx* fc, const rt_tile_request* rq, uint
 }
 RT_API int rt_frame_ctx_release_buffer(rt_frame_ctx* fc) { return guarded([&] { return rt_frame_ctx_release_buffer_impl(fc); }); }
 RT_API void rt_frame_ctx_destroy(rt_frame_ctx* fc) { (void)guarded([&] { return rt_frame_ctx_destroy_impl(fc); }); }
+// debug: the file the library's HIP calls are bound to.  A process may hold two HIP runtimes — PyTorch wheels bundle their own
+// libamdhip64.so (no SONAME), this library asks for ROCm's libamdhip64.so.7 — and the dynamic loader binds this library's hip*
+// symbols to whichever came FIRST in the global scope (profiles/README.md, "two HIP runtimes in one process").  bench.py and
+// the tests use this to create streams with the same runtime and to refuse a process in which torch and the library would
+// drive the device through different ones.  Returns the length of the path (0: unknown).
+extern "C" __attribute__((visibility("default"))) size_t rt_debug_hip_runtime(char* buf, size_t cap) {
+    Dl_info info;
+    std::memset(&info, 0, sizeof info);
+    if (!dladdr(reinterpret_cast<const void*>(&hipGetDeviceCount), &info) || !info.dli_fname) return 0;
+    const size_t n = std::strlen(info.dli_fname);
+    if (buf && cap) {
+        const size_t m = n < cap - 1 ? n : cap - 1;
+        std::memcpy(buf, info.dli_fname, m);
+        buf[m] = 0;
+    }
+    return n;
+}
 // test hook (tests/test_abi.py, not part of rt_tile.h): throw inside a guarded body; the status comes back, nothing unwinds
 extern "C" __attribute__((visibility("default"))) int rt_debug_throw(int kind) {
     return guarded([&]() -> int {

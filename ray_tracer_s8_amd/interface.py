@@ -103,6 +103,7 @@ def init() -> int:
     lib = _abi.load()
     n = C.c_int(0)
     _abi.check(lib.rt_init(C.byref(n)), "rt_init")
+    _abi.check_single_hip_runtime()          # torch imported after the library was bound to ROCm's runtime: say so now
     _initialised = True
     return n.value
 

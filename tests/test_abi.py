@@ -260,3 +260,22 @@ def test_library_records_its_compile_flags(monkeypatch):
     assert build.flags_record() != build.flags_record([]) and "-DRT_PROFILE_TIME" in build.flags_record()
     entry = (ROOT / "__graft_entry__.py").read_text()
     assert "built_with_default_flags()" in entry
+
+
+def test_two_hip_runtimes_in_one_process_are_refused():
+    """Round 2 left an unexplained `torch.cuda.Stream()` -> "no ROCm-capable device" after 122 tests of this library.  Cause
+    (profiles/README.md): the torch wheel bundles its own libamdhip64.so (no SONAME), the library asks for ROCm's
+    libamdhip64.so.7; the loader binds the library's hip* symbols to whichever runtime is in the global scope FIRST.  torch
+    first: one runtime serves both (bench.py's order).  Library first, torch later: two runtimes, the second finds no
+    device.  rt.init() now refuses that order with a message instead of leaving torch to fail later."""
+    import subprocess, sys
+    code_ok = ("import torch; from ray_tracer_s8_amd import _abi; import os; "
+               "p = _abi.hip_runtime_path(); _abi.check_single_hip_runtime(); "
+               "print('BOUND', os.path.dirname(os.path.realpath(p)) == os.path.realpath(os.path.join(os.path.dirname(torch.__file__), 'lib')))")
+    r = subprocess.run([sys.executable, "-c", code_ok], capture_output=True, text=True, cwd=str(ROOT), timeout=300)
+    assert r.returncode == 0 and "BOUND True" in r.stdout, r.stdout + r.stderr
+    code_bad = ("from ray_tracer_s8_amd import _abi; p = _abi.hip_runtime_path(); import torch\n"
+                "try:\n    _abi.check_single_hip_runtime(); print('ACCEPTED', p)\n"
+                "except RuntimeError as e:\n    print('REFUSED', 'two HIP runtimes' in str(e), p)")
+    r = subprocess.run([sys.executable, "-c", code_bad], capture_output=True, text=True, cwd=str(ROOT), timeout=300)
+    assert r.returncode == 0 and "REFUSED True" in r.stdout and "/opt/rocm" in r.stdout, r.stdout + r.stderr

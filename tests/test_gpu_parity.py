@@ -494,8 +494,8 @@ def test_capped_stack_launches_on_two_streams(ndev, oracle, cull):
     """The capped-stack walk (stack entries beyond a few LDS slots live in one per-scene HBM area) enqueued on two
     streams at once: the library chains such launches, so frames rendered 'concurrently' are still exact.  Both the plain
     and the culled walk have a capped-stack variant."""
-    hip = C.CDLL("libamdhip64.so")
     rt.init()
+    hip = _abi.hip_runtime()                 # the runtime the library is bound to (never a second one: profiles/README.md)
     prev = [_abi.debug_set("RT_FORCE_CAPPED", 1), _abi.debug_set("RT_STACK_LDS", 3)]
     try:
         _capped_two_streams(hip, oracle, cull)
