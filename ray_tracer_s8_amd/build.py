@@ -14,7 +14,10 @@ PKG = Path(__file__).resolve().parent
 ROOT = PKG.parent
 CSRC = PKG / "csrc"
 LIB_DIR = PKG / "lib"
-LIB_PATH = LIB_DIR / "librt_s8.so"
+# RT_LIB_VARIANT=<name> (experiments): build and load lib/librt_s8_<name>.so with RT_EXTRA_HIPCC_FLAGS, objects in their own
+# directory — the product library lib/librt_s8.so is never rebuilt in place by an A/B run (round-2 advisor)
+VARIANT = os.environ.get("RT_LIB_VARIANT", "")
+LIB_PATH = LIB_DIR / (f"librt_s8_{VARIANT}.so" if VARIANT else "librt_s8.so")
 
 # -ffp-contract=off: the kernel must perform the reference's IEEE binary32 operations one
 # by one (Rust never contracts a*b+c); FMA appears only where written as __builtin_fmaf.
@@ -47,7 +50,7 @@ def _deps() -> list[Path]:
                                             Path(__file__)]
 
 
-FLAGS_PATH = LIB_DIR / "librt_s8.flags"      # the exact compile lines of the library next to it
+FLAGS_PATH = LIB_PATH.with_suffix(".flags")      # the exact compile lines of the library next to it
 
 
 def _extra_flags() -> list[str]:
@@ -72,6 +75,8 @@ def built_with_default_flags() -> bool:
 def needs_build() -> bool:
     if not LIB_PATH.exists() or not FLAGS_PATH.exists():
         return True
+    if VARIANT and "RT_EXTRA_HIPCC_FLAGS" not in os.environ:
+        return False          # a prebuilt experiment variant is used as it was built (its flags are in its record)
     if FLAGS_PATH.read_text() != flags_record():
         return True
     t = LIB_PATH.stat().st_mtime
@@ -87,7 +92,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     extra = _extra_flags()
     if FLAGS_PATH.exists():
         FLAGS_PATH.unlink()                       # no record while the objects are in flux
-    obj_dir = LIB_DIR / "obj"
+    obj_dir = LIB_DIR / (f"obj_{VARIANT}" if VARIANT else "obj")
     obj_dir.mkdir(exist_ok=True)
     common = [f for f in HIPCC_FLAGS if f != "-shared"] + extra + [f"-I{ROOT / 'include'}", f"-I{CSRC}"]
     cmds, objs = [], []

@@ -286,8 +286,8 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     bool ltree_fits = false;
     const size_t lt_lane = ((size_t)rtk::MAXL_LTREE + (size_t)(rq->max_bounces + 1) + (size_t)(sc->bvh_depth + 2)) * sizeof(uint16_t);
     if (traverse && ltree_env && !(rq->flags & RT_FLAG_NO_LDS_TREE) && sc->n_internal > 0 && n_prims <= 0x7fffu &&
-        ((size_t)sc->n_internal + 1) * rtk::LNODE_DW < 0x8000u) {
-        const size_t fixed = ((size_t)sc->n_internal + 1) * (rtk::LNODE_DW * 4) + lt_lane * rtk::LTREE_BLOCK;   // + the DONE node
+        ((size_t)sc->n_internal + 2) * rtk::LNODE_DW < 0x8000u) {
+        const size_t fixed = ((size_t)sc->n_internal + 2) * (rtk::LNODE_DW * 4) + lt_lane * rtk::LTREE_BLOCK;   // + the DONE and MISS nodes
         ltree_fits = fixed <= LDS_LIMIT;
     }
     // (Below the threshold a DENSE sphere scene whose tree does not fit LDS also takes the quantised nodes, for the culled
@@ -381,7 +381,7 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     const int bs = ltree ? rtk::LTREE_BLOCK : rtk::BLOCK;
     if (ltree) {
         // [nodes][leaf lists u16][path u16][stack u16]
-        size_t off = (((size_t)sc->n_internal + 1) * (rtk::LNODE_DW * 4) + 15) & ~(size_t)15;
+        size_t off = (((size_t)sc->n_internal + 2) * (rtk::LNODE_DW * 4) + 15) & ~(size_t)15;
         p.lds_cand_off = (uint32_t)off;
         off += (size_t)rtk::MAXL_LTREE * bs * sizeof(uint16_t);
         p.lds_path_off = (uint32_t)off;

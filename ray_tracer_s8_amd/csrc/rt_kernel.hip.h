@@ -573,9 +573,11 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
         // each axis and child the three dwords (lo, hi, lo), so that a two-dword read at dword offset s = (d.axis < 0)
         // returns (near, far) = (aabb[sign], aabb[1 - sign]) — literally ray.rs:175-176 — with no min / max / select in
         // the step.  Dwords: l.x 0-2, r.x 3-5, l.y 6-8, r.y 9-11, l.z 12-14, r.z 15-17, 18 = left | right << 16 (16-bit
-        // references, leaf flag 0x8000; a node reference is the node's offset in dwords).  Entry n_internal is node DONE: NaN planes.
+        // references, leaf flag 0x8000; a node reference is the node's offset in dwords).  Two dummies follow the tree (see the
+        // step): entry n_internal is node DONE — its left box is all of space and its left child is DONE itself, its right box
+        // NaN — and entry n_internal + 1, the LAST one, is node MISS, NaN planes throughout.
         float* ln = reinterpret_cast<float*>(lds_raw + p.lds_node_off);
-        for (uint32_t n = tid; n <= p.n_internal; n += BLOCK) {
+        for (uint32_t n = tid; n <= p.n_internal + 1u; n += BLOCK) {
             float* q = ln + LNODE_DW * n;
             if (n < p.n_internal) {
                 const float4 a0 = p.trav[4u * n], a1 = p.trav[4u * n + 1], a2 = p.trav[4u * n + 2], a3 = p.trav[4u * n + 3];
@@ -586,8 +588,10 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
                 q[12] = a0.z; q[13] = a1.z; q[14] = a0.z; q[15] = a2.z; q[16] = a3.z; q[17] = a2.z;
                 q[18] = __uint_as_float(ref16(__float_as_uint(a0.w)) | (ref16(__float_as_uint(a1.w)) << 16));
             } else {
-                const float qn = __builtin_nanf("");
+                const float qn = __builtin_nanf(""), inf = __builtin_inff();
                 for (int i = 0; i < 18; i++) q[i] = qn;
+                if (n == p.n_internal)                        // DONE: the left box (lo, hi, lo) per axis = (-inf, +inf, -inf)
+                    for (int a = 0; a < 3; a++) { q[6 * a] = -inf; q[6 * a + 1] = inf; q[6 * a + 2] = -inf; }
                 q[18] = __uint_as_float((p.n_internal * (uint32_t)LNODE_DW) * 0x10001u);
             }
         }
@@ -838,7 +842,10 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
                 sm = x1 * x1 + x2 * x2;
                 if (bounce ? !(sm >= 1.0f) : (sm <= 1.0f)) break;
             }
-            V3 xdir;
+            // (the two kinds also END alike — bounce: try_normalize(scatter).unwrap_or(n), main.rs:126; camera:
+            // normalize_or_zero(focal_point - o), camera.rs:127 — so that one copy of that normalisation serves both arms: the
+            // arms run one after the other at about half the lanes each, what follows them at all of them)
+            V3 xdir, pre, fallback;
             LCOUNT(2);
             if (bounce) {
                 LCOUNT(3);
@@ -846,8 +853,8 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
                 const V3 us = mk(x1 * factor, x2 * factor, 1.0f - 2.0f * sm);
                 const V3 diffuse_dir = us + bn;
                 const V3 glossy_dir = d - (2.0f * dot(d, bn)) * bn;                    // main.rs:120-121
-                const V3 scatter = diffuse_dir + brough * (glossy_dir - diffuse_dir); // main.rs:122
-                if (!try_normalize(scatter, xdir)) xdir = bn;                          // main.rs:126
+                pre = diffuse_dir + brough * (glossy_dir - diffuse_dir);               // main.rs:122
+                fallback = bn;                                                         // main.rs:126
                 // o is already the hit point P (origin exactly P)
             } else {
                 LCOUNT(4);
@@ -858,10 +865,12 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
                 const V3 d1 = normalize(dir0);                     // Ray::new re-normalises (ray.rs:134)
                 const V3 focal_point = corg + p.focus_distance * d1;
                 o = corg + offset;
-                xdir = normalize_or_zero(focal_point - o);
+                pre = focal_point - o;
+                fallback = mk(0.f, 0.f, 0.f);                      // normalize_or_zero
                 depth_left = p.depth;
                 k = 0;
             }
+            if (!try_normalize(pre, xdir)) xdir = fallback;
             d = normalize(xdir);                                   // Ray::new (ray.rs:134)
             need_ray = false;
             bounce = false;
@@ -1097,16 +1106,22 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
             // and branches included, and the earlier step (a dozen exec regions: leaf / internal, push, pop, list
             // append, emptiness and fullness tests) spent more instructions on control than on the two slab tests.
             // Here every lane of the block runs the same straight line and the state advances through selects:
-            //   * node DONE (= n_internal) is a dummy whose boxes are NaN: no ray enters it.  Stack slot 0 holds DONE
-            //     for good and t_sp >= 1, so popping the empty stack yields DONE, and DONE pops DONE: a finished lane
-            //     idles there until the block ends — no emptiness test, no per-lane exit;
-            //   * a lane at a leaf gathers DONE too, so its two slab results are false and it pops;
+            //   * stack slot 0 holds the reference DONE for good and t_sp >= 1, so popping the empty stack yields DONE.  Node
+            //     DONE (= n_internal) is a dummy that leads back to itself: its left box is all of space ((-inf - o) * inv and
+            //     (+inf - o) * inv are -+inf for every finite non-zero inv), its left child is DONE, its right box is NaN.  A
+            //     finished lane idles there until the block ends — no emptiness test, no per-lane exit, and (round 3) no clamp
+            //     of the stack pointer: the lane neither pushes nor pops.  A lane whose inverse direction is not finite may
+            //     miss even that box (-inf * -inf); it walks the SLOW variant, which keeps the clamp, and there DONE pops DONE;
+            //   * a lane at a leaf gathers node MISS (= n_internal + 1, NaN planes: no ray enters), so both slab results are
+            //     false and it pops.  MISS is the last node and every leaf reference (flag 0x8000) is larger than its offset,
+            //     so the node to gather is min(reference, MISS): one instruction;
             //   * the right child is stored to stack[t_sp], the next free slot, pushed or not (t_sp += both);
             //   * a leaf is stored to list[t_cnt], anything else to that same free stack slot (overwritten next);
             //   * the leaf list has room for a whole block of appends (checked between blocks): no fullness test.
             // The crate's literal slab test (a +-0 direction component, or RT_FLAG_FULL_CHAIN) is chosen per BLOCK of
             // steps for the whole wave: it is the reference's own test, valid for every lane.
             const uint32_t DONE = p.n_internal * (uint32_t)LNODE_DW;            // node references are offsets in dwords
+            const uint32_t MISS = DONE + (uint32_t)LNODE_DW;
             constexpr int STEPS = RT_STEPS_PER_CHECK_LTREE;
             static_assert(MAXL_LTREE > STEPS, "the leaf list must take a block of appends");
             // Inside a block the stack pointer and the list length are carried as LDS byte addresses (top_a: the lane's top
@@ -1123,8 +1138,8 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
             auto step = [&](auto slow_tag) {
                 constexpr bool SLOW = decltype(slow_tag)::value;
                 const bool is_leaf = t_ref > 0x7fffu;
-                const uint32_t ni = is_leaf ? DONE : t_ref;
-                if (STATS) n_int += (ni != DONE) ? 1u : 0u;
+                const uint32_t ni = min(t_ref, MISS);
+                if (STATS) n_int += (ni < DONE) ? 1u : 0u;
                 const uint32_t top = (uint32_t)lds16(top_a);
                 WCOUNT(5);
                 LCOUNT(5);
@@ -1138,8 +1153,50 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
                 const float p0 = fx[0], p1 = fx[1], p2 = fx[3], p3 = fx[4], p4 = fy[0], p5 = fy[1], p6 = fy[3], p7 = fy[4];
                 const float p8 = fz[0], p9 = fz[1], p10 = fz[3], p11 = fz[4];
                 const uint32_t refs = __float_as_uint(nd[18]);
+#ifdef RT_PROBE_LT_LDS64
+                // timing probe: RT_PROBE_LT_LDS64 (1..4) more 8-byte-aligned single ds_read_b64 of the node's neighbourhood per step
+                // (inline asm: the compiler would merge neighbours into ds_read2_b64, which runs at half the rate); consumed
+                // at the end of the step, after the step's own waits
+                typedef float f2_ __attribute__((ext_vector_type(2)));
+                f2_ e0_, e1_, e2_, e3_;
+                {
+                    const uint32_t a_ = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const float*)(lnodes + (ni & ~1u));
+                    asm volatile("ds_read_b64 %0, %1" : "=v"(e0_) : "v"(a_));
+                    if (RT_PROBE_LT_LDS64 > 1) asm volatile("ds_read_b64 %0, %1 offset:8" : "=v"(e1_) : "v"(a_));
+                    if (RT_PROBE_LT_LDS64 > 2) asm volatile("ds_read_b64 %0, %1 offset:16" : "=v"(e2_) : "v"(a_));
+                    if (RT_PROBE_LT_LDS64 > 3) asm volatile("ds_read_b64 %0, %1 offset:24" : "=v"(e3_) : "v"(a_));
+                }
+#endif
+#ifdef RT_PROBE_LT_LDS
+                // timing probe (never in a product build): RT_PROBE_LT_LDS more dword reads of the node per step, results discarded
+                {
+                    float e_[RT_PROBE_LT_LDS];
+#pragma unroll
+                    for (int i = 0; i < RT_PROBE_LT_LDS; i++) e_[i] = nd[(2 + 3 * i) % 18];
+#pragma unroll
+                    for (int i = 0; i < RT_PROBE_LT_LDS; i++) asm volatile("" ::"v"(e_[i]));
+                }
+#endif
                 // all seven reads in flight before the first use (the scheduler, short of registers, serialised them)
                 __builtin_amdgcn_sched_barrier(0);
+#ifdef RT_PROBE_LT_VALU
+                // timing probe: RT_PROBE_LT_VALU more independent v_add_f32 per step (four chains), results discarded
+                {
+                    float a_[4] = {p0, p1, p2, p3};
+#pragma unroll
+                    for (int i = 0; i < RT_PROBE_LT_VALU; i++) a_[i & 3] = a_[i & 3] + o.y;
+                    asm volatile("" ::"v"(a_[0]), "v"(a_[1]), "v"(a_[2]), "v"(a_[3]));
+                }
+#endif
+#ifdef RT_PROBE_LT_VSLOW
+                // timing probe: RT_PROBE_LT_VSLOW more independent v_max_f32 per step
+                {
+                    float a_[4] = {p0, p1, p2, p3};
+#pragma unroll
+                    for (int i = 0; i < RT_PROBE_LT_VSLOW; i++) a_[i & 3] = __builtin_fmaxf(a_[i & 3], a_[(i + 1) & 3]);
+                    asm volatile("" ::"v"(a_[0]), "v"(a_[1]), "v"(a_[2]), "v"(a_[3]));
+                }
+#endif
                 const float lxn = (p0 - o.x) * aux.inv.x, lxf = (p1 - o.x) * aux.inv.x;
                 const float rxn = (p2 - o.x) * aux.inv.x, rxf = (p3 - o.x) * aux.inv.x;
                 const float lyn = (p4 - o.y) * aux.inv.y, lyf = (p5 - o.y) * aux.inv.y;
@@ -1159,8 +1216,16 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
                 lds16(top_a + SLOT) = (uint16_t)cr;                // right subtree after the whole left subtree
                 const bool any = hl || hr;
                 t_ref = any ? (hl ? cl : cr) : top;
-                top_a = max(top_a + ((hl && hr) ? SLOT : 0u) - (any ? 0u : SLOT), stack0_a);
+                top_a = top_a + ((hl && hr) ? SLOT : 0u) - (any ? 0u : SLOT);
+                if (SLOW) top_a = max(top_a, stack0_a);          // (DONE may pop here: see above)
                 cnt_m += is_leaf ? SLOT : 0u;
+#ifdef RT_PROBE_LT_LDS64
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                asm volatile("" ::"v"(e0_));
+                if (RT_PROBE_LT_LDS64 > 1) asm volatile("" ::"v"(e1_));
+                if (RT_PROBE_LT_LDS64 > 2) asm volatile("" ::"v"(e2_));
+                if (RT_PROBE_LT_LDS64 > 3) asm volatile("" ::"v"(e3_));
+#endif
             };
             for (;;) {
                 const uint32_t walking = (uint32_t)__builtin_popcountll(__ballot(in_trav));
@@ -1178,7 +1243,7 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
 #pragma unroll
                         for (int rep = 0; rep < STEPS; rep++) step(std::false_type{});
                     }
-                    t_sp = (top_a - stack0_a) / SLOT + 1u;
+                    t_sp = (top_a + SLOT - stack0_a) / SLOT;       // (0 for a lane that finished: its pop of DONE went below slot 0)
                     t_cnt = (cnt_m - list0_m) / SLOT;
                     in_trav = t_ref != DONE;
                 }
@@ -1556,27 +1621,39 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
             float term_r, term_g, term_b;
             bool finished;
             LCOUNT(7);
-            if (h.idx >= 0) {
+            // Both outcomes need one normalize_or_zero — of (P - centre) / the triangle's face vector for the normal of a hit
+            // (sphere.rs:49-51, mesh.rs:163-165), of the direction for the sky (main.rs:136) — so the vector is chosen per
+            // lane first and ONE copy of the normalisation runs at all the lanes (the two arms run at about half of them each).
+            const bool hit = h.idx >= 0;
+            float em = 0.f;
+            float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+            V3 hp = o, nv = d;
+            if (hit) {
                 WCOUNT(8);
                 LCOUNT(8);
-                const float em = at32(p.emis, (uint32_t)h.idx);
-                const float4 m = at32(p.mat, (uint32_t)h.idx);
+                em = at32(p.emis, (uint32_t)h.idx);
+                m = at32(p.mat, (uint32_t)h.idx);
+                if (!(em > 0.0f)) {
+                    hp = o + h.t * d;                                                  // Ray::at (ray.rs:147-149), as in consider
+                    if ((uint32_t)h.idx < p.n_sph) {
+                        float4 g = at32(p.geom, (uint32_t)h.idx);
+                        nv = hp - mk(g.x, g.y, g.z);                                   // sphere.rs:49-51
+                    } else {
+                        const float* tv = p.tri + 9 * (size_t)(h.idx - p.n_sph);
+                        V3 A = mk(tv[0], tv[1], tv[2]), B = mk(tv[3], tv[4], tv[5]), C = mk(tv[6], tv[7], tv[8]);
+                        nv = cross(A - B, A - C);                                      // mesh.rs:163-165
+                    }
+                }
+            }
+            const V3 nn = normalize_or_zero(nv);
+            if (hit) {
                 if (em > 0.0f) {                              // main.rs:116-117
                     term_r = m.x * em;
                     term_g = m.y * em;
                     term_b = m.z * em;
                     finished = true;
                 } else {
-                    V3 n;
-                    const V3 hp = o + h.t * d;                                       // Ray::at (ray.rs:147-149), as in consider
-                    if ((uint32_t)h.idx < p.n_sph) {
-                        float4 g = at32(p.geom, (uint32_t)h.idx);
-                        n = normalize_or_zero(hp - mk(g.x, g.y, g.z));               // sphere.rs:49-51
-                    } else {
-                        const float* tv = p.tri + 9 * (size_t)(h.idx - p.n_sph);
-                        V3 A = mk(tv[0], tv[1], tv[2]), B = mk(tv[3], tv[4], tv[5]), C = mk(tv[6], tv[7], tv[8]);
-                        n = normalize_or_zero(cross(A - B, A - C));                  // mesh.rs:163-165
-                    }
+                    const V3 n = nn;
                     // push the hit on the path stack: albedo product is applied back-to-front
                     if (p.path32)
                         reinterpret_cast<uint32_t*>(lpath)[k * BLOCK + tid] = (uint32_t)h.idx;
@@ -1609,7 +1686,7 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
                 WCOUNT(11);
                 LCOUNT(9);
                 // sky (main.rs:135-144)
-                float t = normalize_or_zero(d).y * 0.5f + 1.0f;
+                float t = nn.y * 0.5f + 1.0f;
                 float omt = 1.0f - t;
                 term_r = 1.0f * t + 0.3f * omt;
                 term_g = 1.0f * t + 0.3f * omt;

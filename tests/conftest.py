@@ -18,3 +18,10 @@ def oracle():
     from oracle import oracle as orc
     orc.load()
     return orc
+
+
+@pytest.fixture(scope="session")
+def ndev():
+    """rt_init() on the GPU box: the device count (GPU tests only; raises without a HIP device)."""
+    import ray_tracer_s8_amd as rt
+    return rt.init()

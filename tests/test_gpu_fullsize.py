@@ -18,11 +18,6 @@ from ray_tracer_s8_amd import _abi, scenes
 TOL_MEAN_ABS = 1e-5      # BASELINE.json: mean per-channel |delta| <= 1e-5 vs CPU (we get 0)
 
 
-@pytest.fixture(scope="module")
-def ndev():
-    return rt.init()
-
-
 def _frame_gpu(sph, rq, want_f32=False, flags=0):
     reqs = []
     for k in range(rq.divisions):

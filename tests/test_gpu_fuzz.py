@@ -26,11 +26,6 @@ ENGINE_FLAGS = [0, _abi.RT_FLAG_LINEAR_SCAN, _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT
                 _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_EXACT_NODES | _abi.RT_FLAG_NO_LDS_TREE | _abi.RT_FLAG_CULL_WALK | _abi.RT_FLAG_FULL_CHAIN]
 
 
-@pytest.fixture(scope="module")
-def ndev():
-    return rt.init()
-
-
 def _random_case(i):
     g = np.random.default_rng(1000 + i)
     n_sph = int(g.choice([0, 1, 2, 7, 33, 200, 700, 2500]))

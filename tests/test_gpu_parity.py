@@ -14,11 +14,6 @@ from ray_tracer_s8_amd import _abi, scenes
 TOL_MEAN_ABS = 1e-5      # BASELINE.json north_star: mean per-channel |delta| <= 1e-5 vs CPU
 
 
-@pytest.fixture(scope="module")
-def ndev():
-    return rt.init()
-
-
 def _small(name, w, h, spp=None, div=1):
     sph, rq = scenes.config(name)
     rq.width, rq.height, rq.divisions = w, h, div
