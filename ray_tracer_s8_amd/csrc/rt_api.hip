@@ -410,6 +410,7 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     p.t_min = rq->t_min;
     p.t_max = rq->t_max;
     p.spp_f = (float)rq->spp;
+    p.spp_rcp = (rq->spp & (rq->spp - 1u)) == 0u ? 1.0f / (float)rq->spp : 0.0f;   // a power of two up to 2^31: exact in f32
     p.geom_pk = sc->d_geom_pk;
     p.geom_px = sc->d_geom_px;
     p.geom = sc->d_geom;

@@ -138,6 +138,7 @@ struct KParams {
     float u_den, v_den;          // aspect*H_f - 1, H_f - 1 (camera.rs:115-117)
     float t_min, t_max;
     float spp_f;
+    float spp_rcp;               // 1 / spp when spp is a power of two (then x / spp == x * spp_rcp bit for bit), else 0
     const float4* geom_pk;       // [n_sph_pad/2][2]: (c0x,c1x,c0y,c1y) (c0z,c1z,rr0,rr1)
     const float4* geom_px;       // expanded form: (c0x,c1x,c0y,c1y) (c0z,c1z,w0,w1),
                                  //   w = |c|^2 - rr - 2^-16 (|c|^2 + rr)
@@ -813,7 +814,15 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
                         strip = tile_strip | (tile_slot << 8);       // strip index in the batch, staging slot of the pixel's tile
                         const uint32_t yg = tile_yg0 + y;                         // main.rs:66-68
                         pyg = yg;
+#ifdef RT_PROBE_CHEAP_SEED
+                        // timing probe (wrong images): what would acquisition cost without the five SplitMix64 rounds per pixel?
+                        {
+                            const uint64_t h_ = tile_seed + ((uint64_t)yg * p.W + x + 1) * PHI;
+                            rng.s0 = h_; rng.s1 = h_ ^ 0x9e3779b9ull; rng.s2 = ~h_; rng.s3 = h_ + 12345u;
+                        }
+#else
                         rng = seed_pixel(tile_seed, (uint64_t)yg * p.W + x);
+#endif
                         sum_r = sum_g = sum_b = 0.f;
                         s_idx = 0;
                         have_pixel = true;
@@ -1716,9 +1725,24 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
                     WCOUNT(14);
                     LCOUNT(12);
                     // ---- mean, gamma, quantise, store (main.rs:78-81)
-                    float r = __builtin_sqrtf(sum_r / p.spp_f);
-                    float g = __builtin_sqrtf(sum_g / p.spp_f);
-                    float b = __builtin_sqrtf(sum_b / p.spp_f);
+#ifdef RT_PROBE_CHEAP_FINAL
+                    // timing probe (wrong images): the pixel's mean / gamma without the three divisions and square roots
+                    float r = sum_r * 0.1f, g = sum_g * 0.1f, b = sum_b * 0.1f;
+#else
+                    // pix_color / sample_count (main.rs:78-80).  When the sample count is a power of two the quotient IS the
+                    // product with its exact reciprocal (one rounding of the same real value either way, subnormal results
+                    // included), and a multiply is a tenth of an IEEE division's instructions: wave-uniform choice.
+                    float r, g, b;
+                    if (p.spp_rcp != 0.0f) {
+                        r = __builtin_sqrtf(sum_r * p.spp_rcp);
+                        g = __builtin_sqrtf(sum_g * p.spp_rcp);
+                        b = __builtin_sqrtf(sum_b * p.spp_rcp);
+                    } else {
+                        r = __builtin_sqrtf(sum_r / p.spp_f);
+                        g = __builtin_sqrtf(sum_g / p.spp_f);
+                        b = __builtin_sqrtf(sum_b / p.spp_f);
+                    }
+#endif
                     const uint32_t pslot = strip >> 8, sidx = strip & 0xffu;
                     size_t oidx = ((size_t)(pyg - p.strips[sidx].y0) * p.W + px) * 3;      // row within the strip
                     if (!CAN_STAGE || pslot == STAGE_DIRECT) {

@@ -2,10 +2,14 @@
 """Phase census: build with -DRT_PROFILE_PHASES, render one c3 frame, print per-wave-iteration counts."""
 import ctypes as C, os, sys
 sys.path.insert(0, ".")
-os.environ["RT_EXTRA_HIPCC_FLAGS"] = "-DRT_PROFILE_PHASES " + os.environ.get("RT_PT_FLAGS", "")
+# an instrumented VARIANT beside the product library (lib/librt_s8_pcensus.so): the product library is never rebuilt in place
+os.environ["RT_LIB_VARIANT"] = "pcensus" + os.environ.get("RT_PT_TAG", "")
 from ray_tracer_s8_amd import build
-build.build(force=True)
-import numpy as np, torch
+if not build.LIB_PATH.exists() or os.environ.get("RT_PT_FLAGS") is not None:
+    os.environ["RT_EXTRA_HIPCC_FLAGS"] = "-DRT_PROFILE_PHASES " + os.environ.get("RT_PT_FLAGS", "")
+    build.build(force=True)
+    del os.environ["RT_EXTRA_HIPCC_FLAGS"]
+import numpy as np
 import ray_tracer_s8_amd as rt
 from ray_tracer_s8_amd import scenes, _abi
 rt.init()
@@ -20,7 +24,7 @@ with rt.Scene(0, rt.World(sph, tri)) as sc:
     outs, _, st = sc.render_tiles(reqs)
     lib = _abi.load()
     # read raw counters through a tiny HIP memcpy via torch (device pointer is internal) -> use hip runtime
-    hip = C.CDLL("libamdhip64.so")
+    hip = _abi.hip_runtime()
     # counters pointer is not exported; re-render with stats only: use rt_debug_counters
     buf = (C.c_ulonglong * 32)()
     lib.rt_debug_read_counters.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
@@ -38,5 +42,3 @@ with rt.Scene(0, rt.World(sph, tri)) as sc:
     for i, n in enumerate(lnames):
         if lbuf[32 + i]:
             print(f"  {n:28s} executions/iter {lbuf[32 + i] / it:7.3f}   mean active lanes {lbuf[i] / lbuf[32 + i]:5.1f}")
-os.environ["RT_EXTRA_HIPCC_FLAGS"] = ""
-build.build(force=True)

@@ -3,9 +3,13 @@
 usage: tools/phase_time.py [config] [flags]"""
 import ctypes as C, os, sys
 sys.path.insert(0, ".")
-os.environ["RT_EXTRA_HIPCC_FLAGS"] = "-DRT_PROFILE_TIME " + os.environ.get("RT_PT_FLAGS", "")
+# an instrumented VARIANT beside the product library (lib/librt_s8_ptime.so): the product library is never rebuilt in place
+os.environ["RT_LIB_VARIANT"] = "ptime" + os.environ.get("RT_PT_TAG", "")
 from ray_tracer_s8_amd import build
-build.build(force=True)
+if not build.LIB_PATH.exists() or os.environ.get("RT_PT_FLAGS") is not None:
+    os.environ["RT_EXTRA_HIPCC_FLAGS"] = "-DRT_PROFILE_TIME " + os.environ.get("RT_PT_FLAGS", "")
+    build.build(force=True)
+    del os.environ["RT_EXTRA_HIPCC_FLAGS"]
 import ray_tracer_s8_amd as rt
 from ray_tracer_s8_amd import scenes, _abi
 rt.init()
@@ -15,7 +19,7 @@ for k in range(rq.divisions):
     r = rq.copy(); r.division_no = k; r.flags = int(sys.argv[2]) if len(sys.argv) > 2 else 0; reqs.append(r)
 names = ["pixel acquisition", "ray generation", "traversal steps (+ inline flushes)", "root tests (flush)",
          "shade + finish + store", "loop top / counter drain", "-", "-"]
-hip = C.CDLL("libamdhip64.so")
+hip = _abi.hip_runtime()
 nb = (rq.height // rq.divisions) * rq.width * 3
 with rt.Scene(0, rt.World(sph, tri)) as sc:
     dbuf = C.c_void_p()
@@ -48,5 +52,3 @@ with rt.Scene(0, rt.World(sph, tri)) as sc:
     nw = 256 * 16 if st.engine == 4 else None
     if nw:
         print(f"  longest wave (all launches so far) {ex[0]:.3e} cycles, mean of this launch {tot / nw:.3e}: mean / longest = {tot / nw / max(ex[0], 1):.3f}")
-os.environ["RT_EXTRA_HIPCC_FLAGS"] = ""
-build.build(force=True)
