@@ -463,9 +463,13 @@ __device__ __forceinline__ uint8_t f32_as_u8(float v) {
 // consecutive stamps are charged to the phase named by the stamp that ends the interval; one total per phase in
 // the spare queue slots [8192 + 160 ..].
 #ifdef RT_PROFILE_TIME
-#define TDECL unsigned long long _tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long _tlast = __builtin_amdgcn_s_memtime()
+#define TDECL unsigned long long _tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long _tlast = __builtin_amdgcn_s_memtime(); const unsigned long long _t0 = __builtin_amdgcn_s_memrealtime()
 #define TSTAMP(ph) do { const unsigned long long _n = __builtin_amdgcn_s_memtime(); _tacc[ph] += _n - _tlast; _tlast = _n; } while (0)
-#define TFLUSH do { if ((threadIdx.x & 63) == 0) for (int _i = 0; _i < 8; _i++) atomicAdd(&p.counters[4 + 8192 + 160 + _i], _tacc[_i]); } while (0)
+// (+ per launch: [168] latest wave end, [169] sum of the waves' ends, [170] earliest wave start, [171] waves, [172] sum of the waves'
+//  starts — s_memrealtime: the 100 MHz counter all XCDs share (s_memtime runs per XCD): the tail is waves x [168] - [169])
+#define TFLUSH do { if ((threadIdx.x & 63) == 0) { for (int _i = 0; _i < 8; _i++) atomicAdd(&p.counters[4 + 8192 + 160 + _i], _tacc[_i]); \
+    const unsigned long long _te = __builtin_amdgcn_s_memrealtime(); atomicMax(&p.counters[4 + 8192 + 168], _te); atomicAdd(&p.counters[4 + 8192 + 169], _te); \
+    atomicMin(&p.counters[4 + 8192 + 170], _t0); atomicAdd(&p.counters[4 + 8192 + 171], 1ull); atomicAdd(&p.counters[4 + 8192 + 172], _t0); } } while (0)
 #else
 #define TDECL do { } while (0)
 #define TSTAMP(ph) do { } while (0)
@@ -951,6 +955,11 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
             // shaded / refilled while the stragglers keep their stack (LDS) and resume in the next round.
             auto flush = [&]() {
                 if (BFSTEP) n_cand += t_cnt;                     // (the other steps count at the append)
+                // (Tried in round 3 and dropped on the LDS-tree kernel, tools/experiments/: striking the sure misses from the leaf
+                // lists first with the linear engines' conservative broad-phase test, r03_leaf_prefilter.patch, c3 14 560 -> 14 290;
+                // and the compacted root tests of the exact-node L2 kernel below in the LDS two list slots give back,
+                // r03_ltree_compacted_root_tests.patch: 2.7 % slower than its own per-lane flush, and the kernel that carries both
+                // flushes 12 % slower than the one that carries one — 109 instead of 105 VGPRs, 17 instead of 7 spilled SGPRs.)
 #pragma clang loop unroll(disable)
                 for (uint32_t i = 0; i < t_cnt; i++) {
                     LCOUNT(6);

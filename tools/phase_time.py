@@ -31,24 +31,29 @@ with rt.Scene(0, rt.World(sph, tri)) as sc:
     sc.render_tiles(reqs[:1])
     lib = _abi.load()
     lib.rt_debug_read_counters.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
-    zero = (C.c_ulonglong * 8)()
-    zero8 = None
-    lib.rt_debug_read_counters(sc._h, 4 + 8192 + 160, 8, zero)       # (counters so far: warm-up launches)
+    zero = (C.c_ulonglong * 13)()
+    lib.rt_debug_read_counters(sc._h, 4 + 8192 + 160, 13, zero)      # (counters so far: warm-up launches)
     base = list(zero)
     sc.render_tiles_device(reqs, ptrs, nb)
     hip.hipDeviceSynchronize()
     st = sc.collect()
-    buf = (C.c_ulonglong * 8)()
-    lib.rt_debug_read_counters(sc._h, 4 + 8192 + 160, 8, buf)
-    for i in range(8):
-        buf[i] -= base[i]
+    raw = (C.c_ulonglong * 13)()
+    lib.rt_debug_read_counters(sc._h, 4 + 8192 + 160, 13, raw)
+    buf = [int(raw[i]) - int(base[i]) for i in range(8)]
     tot = sum(buf)
     print(f"segments {st.ray_segments}  kernel {st.kernel_ms:.2f} ms (one launch)  wave cycles {tot:.3e}")
     for i, n in enumerate(names):
         if buf[i]:
             print(f"  {n:36s} {100.0 * buf[i] / tot:6.2f} %")
-    ex = (C.c_ulonglong * 5)()
-    lib.rt_debug_read_counters(sc._h, 4 + 8192 + 168, 5, ex)
-    nw = 256 * 16 if st.engine == 4 else None
-    if nw:
-        print(f"  longest wave (all launches so far) {ex[0]:.3e} cycles, mean of this launch {tot / nw:.3e}: mean / longest = {tot / nw / max(ex[0], 1):.3f}")
+    # wave start / end times of THIS launch (s_memtime, one device clock): the sums and the count accumulate, the latest end
+    # is the last launch's
+    n_w = int(raw[11]) - int(base[11])
+    if os.environ.get("RT_PT_DEBUG"):
+        print("  raw ", [int(v) for v in raw][8:]); print("  base", [int(v) for v in base][8:])
+    if n_w:
+        t_last = int(raw[8])
+        mean_end = (int(raw[9]) - int(base[9])) / n_w
+        mean_start = (int(raw[12]) - int(base[12])) / n_w
+        span = t_last - mean_start
+        print(f"  {n_w} waves (s_memrealtime, 10 ns ticks): mean start -> latest end {span / 100:.1f} us; the mean wave ends "
+              f"{(t_last - mean_end) / 100:.1f} us before the last one = {100.0 * (t_last - mean_end) / span:.1f} % of the span idle at the end")
