@@ -15,6 +15,14 @@ tag, rnd, workload = sys.argv[1], sys.argv[2], (sys.argv[3] if len(sys.argv) > 3
 want = sys.argv[4] if len(sys.argv) > 4 else None
 src = f"gpurun_out/prof_{tag}"
 os.makedirs("profiles", exist_ok=True)
+# gpurun MERGES a call's gpurun_out/ into the local one: files of earlier profile runs of the same tag (other process ids in
+# their names) stay beside the new ones.  Only the newest run counts: everything more than an hour older than the newest
+# file of the directory is ignored (round 3 nearly archived a mixture).
+_all = [f for f in glob.glob(f"{src}/**/*.csv", recursive=True)]
+_newest = max(os.path.getmtime(f) for f in _all)
+_stale = {f for f in _all if os.path.getmtime(f) < _newest - 3600}
+_glob = glob.glob
+glob.glob = lambda pat, **kw: [f for f in _glob(pat, **kw) if f not in _stale]
 stats = None
 for f in glob.glob(f"{src}/trace/**/*kernel_stats.csv", recursive=True):
     shutil.copy(f, f"profiles/{rnd}_{tag}_kernel_stats.csv")

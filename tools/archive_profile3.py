@@ -13,7 +13,7 @@ tag, rnd, workload = sys.argv[1], sys.argv[2], (sys.argv[3] if len(sys.argv) > 3
 want = sys.argv[4] if len(sys.argv) > 4 else None
 src = f"gpurun_out/prof_{tag}"
 subprocess.run([sys.executable, "tools/archive_profile.py", tag, rnd, workload] + ([want] if want else []), check=True)
-trace = sorted(glob.glob(f"{src}/trace/**/*kernel_trace.csv", recursive=True))
+trace = sorted(glob.glob(f"{src}/trace/**/*kernel_trace.csv", recursive=True), key=os.path.getmtime)   # newest run (see archive_profile.py)
 rows = list(csv.DictReader(open(trace[-1])))
 names = {}
 for r in rows:
@@ -34,4 +34,15 @@ out = {"command": cmd, "kernel": kern, "launches_in_trace": len(d), "durations_m
 if line is not None:
     out["trace_vs_line_ratio"] = out["timed_launches_6_to_25_avg_ms"] / line["ms_per_step"]
 json.dump(out, open(f"profiles/{rnd}_{tag}_timed_region.json", "w"), indent=1)
+for name in (f"profiles/{rnd}_hbm_traffic.json", f"profiles/{rnd}_valu_issue.json"):
+    if os.path.exists(name):
+        dd = json.load(open(name))
+        if isinstance(dd.get(workload), dict):
+            dd[workload]["avg_launch_ms_timed_region"] = out["timed_launches_6_to_25_avg_ms"]
+            if "avg_launch_ms_in_trace" in dd[workload]:
+                # the --stats average runs over EVERY launch of that kernel name in the driver's command (the host-buffer pass
+                # launches partial frames, other_workloads renders c4 with the same kernel): not a per-frame figure
+                dd[workload]["stats_average_all_launches_of_that_kernel_ms"] = dd[workload].pop("avg_launch_ms_in_trace")
+            dd[workload]["timed_region"] = f"profiles/{rnd}_{tag}_timed_region.json"
+            json.dump(dd, open(name, "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if k != "durations_ms"}, indent=1))
