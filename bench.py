@@ -11,12 +11,21 @@ collective on the data path either way.  The scene is resident in HBM before the
 to HBM.  Timing: barrier + synchronize on both sides of exactly K steps, MAX over ranks.  value = ray segments of all
 ranks / that time.
 
-Also reported in the same JSON line (DESIGN.md 5):
-  roofline         the timed kernel against the FP32 VALU peak, from work it EXECUTES: for the traversal engines the
+Also reported in the same JSON line (DESIGN.md 5, 6):
+  other_workloads  BASELINE configs c2 / c4 / c5 and the 100 352-triangle mesh through the same device-resident entry point,
+                   three timed launches each after the timed region (rank 0, N = 1): value, engine, ms per frame
+  frame_path       wall clock of the in-process product path that replaces the controller's dispatch + assembly: c3 and c4
+                   frames through a persistent rt_frame_ctx into a host buffer — first frame (pays pin_ms, carries scene_ms)
+                   and a later frame of the job (pays neither): wall / pin / scene / kernel / exposed download / host ms
+  strong_c4        N > 1 only: ONE c4 frame split by strip over the ranks (BASELINE config 4), max-rank time, beside the
+                   weak-scaling value of the line
+  roofline         the timed kernel against the FP32 vector peak, from work it EXECUTES: for the traversal engines the
                    slab tests (48 flop per node visited) and root tests (20 flop per leaf reached), both counted by one
-                   extra launch of the same frame through the kernel's counting twin, outside the timed region; avg
+                   extra launch of the same frame through the kernel's counting twin, outside the timed region, against
+                   the NON-FMA peak (78.65 TFLOP/s: the parity build's slab and root tests are sub / mul / compare); avg
                    launch duration from HIP events recorded by the library on the stream the kernel runs on.  frac <= 1
-                   is asserted.  valu_issue / traffic come from committed PMC passes and say so ("source").
+                   is asserted.  valu_fraction_8d = SURVEY 8(d)'s segments x 20 x N / t / 78.65e12 (> 1 for a traversal
+                   engine: not a hardware fraction).  valu_issue / traffic come from committed PMC passes and say so.
   roofline_linear  the same frame through the north-star-shaped kernel (linear scan over the LDS-resident sphere list),
                    own launches in this run: SURVEY 8(d)'s 20*N flop per segment / launch time
   cpu_baseline     the CPU oracle (BVH back-end = the reference's algorithm) timed on this box's host cores on a
