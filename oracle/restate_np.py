@@ -196,16 +196,25 @@ def pick_t(roots, t_min, t_max):                # S/shapes/mod.rs:106-127
 
 
 class World:
-    def __init__(self, spheres, triangles, t_min=0.001, t_max=1000.0):
+    def __init__(self, spheres, triangles, t_min=0.001, t_max=1000.0, world_index=None):
         self.spheres = [] if spheres is None else list(spheres)
         self.triangles = [] if triangles is None else list(triangles)
+        # `world: Vec<Object>` (S/lib.rs:11) is ONE list; world_index gives the position of every sphere, then of every
+        # triangle, in it (include/rt_tile.h "the world's order"); None: the spheres, then the triangles
+        objs = [("s", ob) for ob in self.spheres] + [("t", ob) for ob in self.triangles]
+        if world_index is None:
+            self.objects = objs
+        else:
+            self.objects = [None] * len(objs)
+            for i, w in enumerate(world_index):
+                self.objects[int(w)] = objs[i]
         self.t_min, self.t_max = F(t_min), F(t_max)
         self.segments = 0
 
     def intersect(self, o, d):                  # S/shapes/mod.rs:158-191
         best = None
-        for kind, objs in (("s", self.spheres), ("t", self.triangles)):
-            for ob in objs:
+        if True:
+            for kind, ob in self.objects:           # front to back through the list
                 roots = sphere_roots(ob, o, d) if kind == "s" else triangle_roots(ob, o, d)
                 t = pick_t(roots, self.t_min, self.t_max)
                 if t is None:
@@ -286,12 +295,12 @@ def as_u8(c):                                   # S/color.rs:13-19, Rust saturat
     return int(v)
 
 
-def render(req, spheres, triangles=None):
+def render(req, spheres, triangles=None, world_index=None):
     """Tile loop S/main.rs:37-83 for strip req.division_no.  Returns (rgb uint8 [Hs,W,3], f32, segments)."""
     W, H = req.width, req.height
     hs = H // req.divisions
     cam = Camera((ZERO, ZERO, ZERO), F(W) / F(H), req.aperture, req.focus_distance, req.fov, req.focal_length, F(H))
-    world = World(spheres, triangles, req.t_min, req.t_max)
+    world = World(spheres, triangles, req.t_min, req.t_max, world_index)
     rgb = np.zeros((hs, W, 3), np.uint8)
     f32 = np.zeros((hs, W, 3), np.float32)
     n = F(req.spp)

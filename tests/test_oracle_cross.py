@@ -8,10 +8,10 @@ from oracle import restate_np
 from ray_tracer_s8_amd import _abi, scenes
 
 
-def _both(oracle, rq, sph, tri=None):
-    rgb, f32, info = oracle.render(rq, sph, tri, backend=0, want_f32=True)
+def _both(oracle, rq, sph, tri=None, world_index=None):
+    rgb, f32, info = oracle.render(rq, sph, tri, backend=0, want_f32=True, world_index=world_index)
     hs = rq.height // rq.divisions
-    rgb2, f2, segs2 = restate_np.render(rq, sph, tri)
+    rgb2, f2, segs2 = restate_np.render(rq, sph, tri, world_index=world_index)
     assert np.array_equal(rgb.reshape(hs, rq.width, 3), rgb2)
     assert np.array_equal(f32.reshape(hs, rq.width, 3).view(np.uint32), f2.view(np.uint32))
     assert info["ray_segments"] == segs2
@@ -33,6 +33,19 @@ def test_cross_triangles(oracle):
     sph, tri = scenes.quad_room()
     rq = _abi.default_request(width=20, height=12, divisions=1, spp=2, max_bounces=5, seed=5)
     _both(oracle, rq, sph, tri)
+
+
+def test_cross_world_order(oracle):
+    """An interleaved world of identical copies (every hit an exact tie: the order of `world` alone picks the winner): the
+    two restatements agree under the same world_index, and differ from the spheres-then-triangles order."""
+    from test_world_order import interleave, tie_world
+    sph, tri = tie_world(7, n_groups=3, dup=3)
+    wi = interleave(len(sph), len(tri), 3)
+    rq = _abi.default_request(width=18, height=12, divisions=1, spp=2, max_bounces=3, seed=2)
+    _both(oracle, rq, sph, tri, wi)
+    a, _, _ = oracle.render(rq, sph, tri, backend=0, world_index=wi)
+    b, _, _ = oracle.render(rq, sph, tri, backend=0)
+    assert not np.array_equal(a, b)
 
 
 def test_cross_rng_stream(oracle):
