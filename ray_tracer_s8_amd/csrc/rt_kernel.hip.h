@@ -1654,7 +1654,7 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
                 if (!(em > 0.0f)) {
                     hp = o + h.t * d;                                                  // Ray::at (ray.rs:147-149), as in consider
                     if ((uint32_t)h.idx < p.n_sph) {
-                        float4 g = at32(p.geom, (uint32_t)h.idx);
+                        float4 g = at32(p.geom, (uint32_t)h.idx);      // (asked for together with the material instead: no gain, measured in round 3)
                         nv = hp - mk(g.x, g.y, g.z);                                   // sphere.rs:49-51
                     } else {
                         const float* tv = p.tri + 9 * (size_t)(h.idx - p.n_sph);
@@ -1715,15 +1715,32 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
                 WCOUNT(12);
                 LCOUNT(10);
                 // a1 (.) (a2 (.) ( ... (ak (.) terminal))) : right-to-left (main.rs:123)
-                for (uint32_t i = k; i-- > 0;) {
-                    WCOUNT(13);
-                    LCOUNT(11);
-                    uint32_t idx = p.path32 ? reinterpret_cast<uint32_t*>(lpath)[i * BLOCK + tid]
-                                            : (uint32_t) reinterpret_cast<uint16_t*>(lpath)[i * BLOCK + tid16];
-                    float4 m = at32(p.mat, (uint32_t)idx);
-                    term_r = m.x * term_r;
-                    term_g = m.y * term_g;
-                    term_b = m.z * term_b;
+                // two materials per round: the loads of a round are independent of each other (the indices come from LDS), so a
+                // pair costs one trip to L2, not two; the products are taken in the same order (c5 +0.4 %, round 3)
+                {
+                    auto path_idx = [&](uint32_t i) -> uint32_t {
+                        return p.path32 ? reinterpret_cast<uint32_t*>(lpath)[i * BLOCK + tid]
+                                        : (uint32_t) reinterpret_cast<uint16_t*>(lpath)[i * BLOCK + tid16];
+                    };
+                    uint32_t i = k;
+#pragma clang loop unroll(disable)
+                    while (i >= 2) {
+                        WCOUNT(13);
+                        LCOUNT(11);
+                        const float4 ma = at32(p.mat, path_idx(i - 1)), mb = at32(p.mat, path_idx(i - 2));
+                        term_r = mb.x * (ma.x * term_r);
+                        term_g = mb.y * (ma.y * term_g);
+                        term_b = mb.z * (ma.z * term_b);
+                        i -= 2;
+                    }
+                    if (i) {
+                        WCOUNT(13);
+                        LCOUNT(11);
+                        const float4 ma = at32(p.mat, path_idx(0));
+                        term_r = ma.x * term_r;
+                        term_g = ma.y * term_g;
+                        term_b = ma.z * term_b;
+                    }
                 }
                 sum_r = sum_r + term_r;                      // pix_color += (main.rs:75)
                 sum_g = sum_g + term_g;
