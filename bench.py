@@ -19,6 +19,8 @@ Also reported in the same JSON line:
                    and a later frame of the job (pays neither): wall / pin / scene / kernel / exposed download / host ms
   strong_c4        N > 1 only: ONE c4 frame split by strip over the ranks (BASELINE config 4), max-rank time, beside the
                    weak-scaling value of the line
+  frame_path_all_devices   N > 1 only: c4 frames through ONE rt_frame_ctx over all N devices inside rank 0 (static split and
+                   strip queue), wall clock: the in-process replacement of the controller's dispatch loop on N GPUs
   roofline         the timed kernel against the FP32 vector peak, from work it EXECUTES: for the traversal engines the
                    slab tests (48 flop per node visited) and root tests (20 flop per leaf reached), both counted by one
                    extra launch of the same frame through the kernel's counting twin, outside the timed region, against
@@ -75,6 +77,8 @@ def parse_args():
     ap.add_argument("--frame", action="store_true", help="print ONLY the frame_path object: wall-clock frames of --workload "
                     "through a persistent rt_frame_ctx (host buffer out), --steps frames after the first")
     ap.add_argument("--frame-queue", action="store_true", help="with --frame: the strip-queue assignment (RT_FLAG_FRAME_QUEUE)")
+    ap.add_argument("--frame-devices", default="", help="with --frame: comma-separated device ordinals of the frame context "
+                    "(default: the rank's device); a device may be listed more than once")
     ap.add_argument("--cpu-scale", type=int, default=1, help="CPU baseline renders the frame at 1/scale resolution")
     ap.add_argument("--flags", type=int, default=0, help="rt_tile_request.flags (1 = exact scan)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -123,7 +127,7 @@ def cpu_baseline(workload: str, scale: int):
     }
 
 
-def frame_path(rt, _abi, scenes, workload: str, dev_index: int, frames: int = 3, queue: bool = False):
+def frame_path(rt, _abi, scenes, workload: str, dev_index, frames: int = 3, queue: bool = False):
     """Wall clock of the in-process product path that replaces the controller's dispatch + assembly (controller
     main.rs:47-75, 109-115): rt_frame_ctx_render into a host frame buffer — kernels, strip downloads, dispatcher
     wake-ups, everything — frame after frame of one job.  Frame 1 carries the one-off costs (page-locking the buffer,
@@ -133,8 +137,9 @@ def frame_path(rt, _abi, scenes, workload: str, dev_index: int, frames: int = 3,
     if queue:
         rq.flags |= _abi.RT_FLAG_FRAME_QUEUE
     buf = np.zeros(rq.width * rq.height * 3, np.uint8)            # (zeros: the pages exist before the first frame)
+    devices = list(dev_index) if isinstance(dev_index, (list, tuple)) else [dev_index]
     t0 = time.perf_counter()
-    fc = rt.FrameContext(devices=[dev_index])
+    fc = rt.FrameContext(devices=devices)
     t1 = time.perf_counter()
     fc.set_world(rt.World(sph, tri))
     t2 = time.perf_counter()
@@ -149,7 +154,8 @@ def frame_path(rt, _abi, scenes, workload: str, dev_index: int, frames: int = 3,
                      "segments": int(fs.totals.ray_segments)})
     fc.close()
     steady = sorted(recs[1:], key=lambda r: r["wall_ms_python"])[len(recs[1:]) // 2]      # median later frame
-    out = {"workload": workload, "n_devices": 1, "assignment": "strip queue" if queue else "static: strip k -> device k mod n",
+    out = {"workload": workload, "n_devices": len(devices), "devices": devices,
+           "assignment": "strip queue" if queue else "static: strip k -> device k mod n",
            "ctx_create_ms": (t1 - t0) * 1e3, "set_world_ms": (t2 - t1) * 1e3,
            "first_frame": recs[0], "steady_frame": steady, "frames_after_first": len(recs) - 1,
            "mrays_per_s": steady["segments"] / (steady["wall_ms_python"] / 1e3) / 1e6,
@@ -230,7 +236,8 @@ def main():
     if args.frame:
         if world != 1:
             raise SystemExit("--frame is the in-process path: run it with --gpus 1")
-        print(json.dumps({"frame_path": frame_path(rt, _abi, scenes, args.workload, dev_index, args.steps, args.frame_queue)}), flush=True)
+        devs = [int(x) for x in args.frame_devices.split(",") if x != ""] or dev_index
+        print(json.dumps({"frame_path": frame_path(rt, _abi, scenes, args.workload, devs, args.steps, args.frame_queue)}), flush=True)
         return
     sph, tri, rq0 = scenes.config_world(args.workload)
     rq0.flags = args.flags
@@ -417,6 +424,31 @@ def main():
                                      "(controller main.rs:47-75), max-rank time"}
             del out4
 
+    # ---- N > 1: the IN-PROCESS product path over all N devices (one rt_frame_ctx in rank 0, one dispatcher thread per GPU; the
+    # other ranks wait at the barrier, their GPUs are idle): c4 frames into a host buffer, wall clock — the controller's
+    # dispatch + assembly replaced in one process, timed on as many GPUs as the line covers
+    fpath_all = None
+    if world > 1 and not args.strong and args.workload == "c3" and not args.no_frame:
+        barrier()
+        if rank == 0:
+            # in a CHILD process (this script with --frame): nothing that goes wrong there — this path has never run on more
+            # than one physical device — can take the scaling line with it
+            devs = ",".join(str(dev_index if args.share_device else d) for d in range(world))
+            env = {k: v for k, v in os.environ.items()
+                   if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR",
+                                "MASTER_PORT", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS")}
+            fpath_all = {}
+            for name, extra in (("static", []), ("strip_queue", ["--frame-queue"])):
+                try:
+                    pr = subprocess.run([sys.executable, str(Path(__file__).resolve()), "--frame", "--workload", "c4", "--steps", "3",
+                                         "--frame-devices", devs] + extra, capture_output=True, text=True, timeout=300, env=env)
+                    last = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
+                    fpath_all[name] = json.loads(last[-1])["frame_path"] if pr.returncode == 0 and last else \
+                        {"error": f"rc {pr.returncode}: {pr.stderr[-400:]}"}
+                except Exception as e:
+                    fpath_all[name] = {"error": repr(e)}
+        barrier()
+
     if rank == 0:
         n_sph = len(sph)
         launches = max(st.n_launches, 1)
@@ -528,6 +560,7 @@ def main():
             "other_workloads": others,
             "frame_path": fpath,
             "strong_c4": strong_c4,
+            "frame_path_all_devices": fpath_all,
         }
         if st.engine in (2, 3, 5, 6):
             # The L2-gather walks are bound by their node gathers, not by flops: beside the FP32 object, the
