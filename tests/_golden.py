@@ -31,8 +31,14 @@ def load_all():
         for k in rec.dtype.names:
             v = rec[k]
             setattr(rq, k, float(v) if rec.dtype[k].kind == "f" else int(v))
-        sph, tri = _scene(f.stem)
-        out.append(dict(name=f.stem, req=rq, spheres=sph, triangles=tri,
+        wi = None
+        if "world_index" in z.files:                     # a vector that carries its own world (arrays + the list's order)
+            sph = np.ascontiguousarray(z["spheres"]).reshape(-1).view(_abi.SPHERE_DTYPE)
+            tri = np.ascontiguousarray(z["triangles"]).reshape(-1).view(_abi.TRIANGLE_DTYPE)
+            wi = z["world_index"].astype(np.uint32)
+        else:
+            sph, tri = _scene(f.stem)
+        out.append(dict(name=f.stem, req=rq, spheres=sph, triangles=tri, world_index=wi,
                         rgb=z["rgb"] if "rgb" in z.files else None,
                         sha256_rgb=str(z["sha256_rgb"]), sha256_f32=str(z["sha256_f32"]),
                         ray_segments=int(z["ray_segments"]),

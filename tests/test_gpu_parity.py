@@ -50,7 +50,7 @@ _GOLDEN = _load_golden()
 @pytest.mark.parametrize("case", _GOLDEN, ids=[c["name"] for c in _GOLDEN])
 def test_gpu_matches_committed_golden(ndev, case):
     """HIP path vs the committed fixture bytes (no oracle call involved)."""
-    with rt.Scene(0, rt.World(case["spheres"], case["triangles"])) as sc:
+    with rt.Scene(0, rt.World(case["spheres"], case["triangles"], case["world_index"])) as sc:
         rl = case["req"].copy()
         rl.flags = rt.RT_FLAG_NO_BVH_CULL
         lin, lin_f, st_l = sc.render_tile(rl, want_f32=True)

@@ -38,7 +38,7 @@ def test_cross_triangles(oracle):
 def test_cross_world_order(oracle):
     """An interleaved world of identical copies (every hit an exact tie: the order of `world` alone picks the winner): the
     two restatements agree under the same world_index, and differ from the spheres-then-triangles order."""
-    from test_world_order import interleave, tie_world
+    from _world_cases import interleave, tie_world
     sph, tri = tie_world(7, n_groups=3, dup=3)
     wi = interleave(len(sph), len(tri), 3)
     rq = _abi.default_request(width=18, height=12, divisions=1, spp=2, max_bounces=3, seed=2)
