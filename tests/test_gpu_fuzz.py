@@ -60,6 +60,22 @@ def _random_case(i):
     return sph, tri, rq, flags
 
 
+def _world_order(i, sph, tri):
+    """Every third case (round 3): the world is given in an order of its own — a random world_index — and a few primitives
+    are made exact copies of others (different albedo), so that hits at exactly equal distance exist and the order decides them.
+    Own generator: the scenes of the other cases stay what they were."""
+    if i % 3 != 1 or len(sph) + len(tri) < 2:
+        return sph, tri, None
+    g = np.random.default_rng(77000 + i)
+    sph, tri = sph.copy(), tri.copy()
+    for arr, geo in ((sph, ("cx", "cy", "cz", "radius")), (tri, ("a", "b", "c"))):
+        for _ in range(min(4, len(arr) // 2)):
+            j, k = g.integers(0, len(arr), 2)
+            for f in geo:
+                arr[f][k] = arr[f][j]
+    return sph, tri, g.permutation(len(sph) + len(tri)).astype(np.uint32)
+
+
 N_CASES = int(os.environ.get("RT_FUZZ_CASES", "66"))      # RT_FUZZ_CASES=1000 for a long soak
 
 
@@ -68,12 +84,13 @@ def test_fuzz_case(ndev, oracle, i):
     sph, tri, rq, flags = _random_case(i)
     if rq.height // rq.divisions == 0:
         pytest.skip("zero-row strip")
+    sph, tri, wi = _world_order(i, sph, tri)
     backend = 0 if (flags & _abi.RT_FLAG_NO_BVH_CULL) else 1
     ref, ref_f, info = oracle.render(rq, sph if len(sph) else None, tri if len(tri) else None, backend=backend,
-                                     want_f32=True)
+                                     want_f32=True, world_index=wi)
     r = rq.copy()
     r.flags = flags
-    with rt.Scene(0, rt.World(sph, tri)) as sc:
+    with rt.Scene(0, rt.World(sph, tri, wi)) as sc:
         rgb, f32, st = sc.render_tile(r, want_f32=True)
     assert np.array_equal(rgb, ref), f"case {i}: {int((rgb != ref).sum())} bytes differ (flags {flags})"
     assert np.array_equal(f32.view(np.uint32), ref_f.view(np.uint32)), f"case {i}"
@@ -167,10 +184,19 @@ def test_fuzz_big_mixed_scene(ndev, oracle, i):
     rq = _abi.default_request(width=192, height=108, divisions=1, spp=2, max_bounces=int(g.choice([3, 6])), seed=int(g.integers(0, 2**63)))
     flags = [0, _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_QUANT_NODES, _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_EXACT_NODES | _abi.RT_FLAG_NO_CULL_WALK,
              _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_EXACT_NODES | _abi.RT_FLAG_CULL_WALK][(i // 4) % 4]
-    ref, ref_f, info = oracle.render(rq, sph, tri, backend=1, want_f32=True)
+    # odd cases: the spheres and triangles interleaved at random in `world` (round 3), a hundred of each made exact copies
+    wi = None
+    if i % 2:
+        gw = np.random.default_rng(88000 + i)
+        for arr, geo in ((sph, ("cx", "cy", "cz", "radius")), (tri, ("a", "b", "c"))):
+            j, k = gw.integers(1, len(arr), 100), gw.integers(1, len(arr), 100)
+            for f in geo:
+                arr[f][k] = arr[f][j]
+        wi = gw.permutation(ns + nt).astype(np.uint32)
+    ref, ref_f, info = oracle.render(rq, sph, tri, backend=1, want_f32=True, world_index=wi)
     r = rq.copy()
     r.flags = flags
-    with rt.Scene(0, rt.World(sph, tri)) as sc:
+    with rt.Scene(0, rt.World(sph, tri, wi)) as sc:
         rgb, f32, st = sc.render_tile(r, want_f32=True)
     assert st.engine in (2, 3, 6)
     assert np.array_equal(rgb, ref), f"mixed case {i}: {int((rgb != ref).sum())} bytes differ (flags {flags}, engine {st.engine})"
