@@ -476,6 +476,16 @@ __device__ __forceinline__ uint8_t f32_as_u8(float v) {
 #define TFLUSH do { } while (0)
 #endif
 
+// The sphere record of the traversal kernels' root tests: (centre, RN(r * r)), formed from the (centre, radius) array that the leaf
+// validation and the culled walk read anyway — one rounded multiply, the host's own `radius * radius` (sphere.rs:45 `radius.powi(2)`)
+// — so that a large scene keeps ONE 16-byte record per sphere in L2 instead of two (round 3: c5's hot set is 2 MB of nodes + 1 MB of
+// materials + these records against 4 MB of L2 per XCD; c5 4 460 -> 4 710 Mrays/s).  -DRT_GEOM_RR reads the (centre, r^2) array as before.
+#ifndef RT_GEOM_RR
+#define RT_SPHERE_REC(p_, prim_) ([&]() { const float4 r_ = at32((p_).geom_r, (prim_)); return make_float4(r_.x, r_.y, r_.z, r_.w * r_.w); }())
+#else
+#define RT_SPHERE_REC(p_, prim_) at32((p_).geom, (prim_))
+#endif
+
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 
@@ -929,7 +939,7 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
                     float t;
                     bool hit;
                     if (prim < p.n_sph) {
-                        const float4 g = at32(p.geom, prim);
+                        const float4 g = RT_SPHERE_REC(p, prim);
                         hit = exact_sphere(o, 2.0f * d, mk(g.x, g.y, g.z), g.w, p.t_min, p.t_max, t);
                     } else {
                         hit = exact_triangle(o, d, p.tri + 9 * (size_t)(prim - p.n_sph), p.t_min, p.t_max, t);
@@ -972,7 +982,7 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
                     // lazily: only to a hit that would replace the running closest one.  (A lane without a finite
                     // inverse direction walked the exact nodes: nothing to validate.)
                     if (prim < p.n_sph) {
-                        const float4 g = at32(p.geom, prim);
+                        const float4 g = RT_SPHERE_REC(p, prim);
                         if (exact_sphere(o, 2.0f * d, mk(g.x, g.y, g.z), g.w, p.t_min, p.t_max, t)) {   // (2f32 * ray.direction), sphere.rs:44
                             if (QNODES)
                                 consider_if<CULL>(h, (int)prim, o, d, t, [&]() {
@@ -1060,7 +1070,7 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
                         const uint32_t ot16 = (ot & ~63u) | ((ot & 31u) << 1) | ((ot >> 5) & 1u);
                         const uint32_t prim = p.list16 ? (uint32_t)lc16[slot * BLOCK + ot16] : lc32[slot * BLOCK + ot];
                         if (prim < p.n_sph) {
-                            const float4 g = at32(p.geom, prim);
+                            const float4 g = RT_SPHERE_REC(p, prim);
                             hit = exact_sphere(ro, 2.0f * rd, mk(g.x, g.y, g.z), g.w, p.t_min, p.t_max, t);   // (2f32 * ray.direction), sphere.rs:44
                         } else {
                             hit = exact_triangle(ro, rd, p.tri + 9 * (size_t)(prim - p.n_sph), p.t_min, p.t_max, t);
@@ -1654,7 +1664,7 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
                 if (!(em > 0.0f)) {
                     hp = o + h.t * d;                                                  // Ray::at (ray.rs:147-149), as in consider
                     if ((uint32_t)h.idx < p.n_sph) {
-                        float4 g = at32(p.geom, (uint32_t)h.idx);      // (asked for together with the material instead: no gain, measured in round 3)
+                        float4 g = TRAVERSE ? RT_SPHERE_REC(p, (uint32_t)h.idx) : at32(p.geom, (uint32_t)h.idx);      // (asked for together with the material instead: no gain, measured in round 3)
                         nv = hp - mk(g.x, g.y, g.z);                                   // sphere.rs:49-51
                     } else {
                         const float* tv = p.tri + 9 * (size_t)(h.idx - p.n_sph);
