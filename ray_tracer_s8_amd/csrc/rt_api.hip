@@ -94,12 +94,13 @@ enum DebugKnob {
     DBG_REFILL_EIGHTHS,    // RT_REFILL_EIGHTHS  refill threshold of the walks; 0: host rule
     DBG_TILE_8X8,          // RT_TILE_SHAPE=8x8  square tiles                                               (default 0)
     DBG_VERBOSE,           // RT_VERBOSE         engine / LDS plan of every launch on stderr                 (default 0)
+    DBG_REORDER,           // RT_REORDER         0: primitive records stay in the caller's order (A/B)          (default 1)
     DBG_N
 };
 std::atomic<int> g_dbg[DBG_N];
 const struct { const char* env; int def; } g_dbg_spec[DBG_N] = {
     {"RT_LDS_TREE", 1}, {"RT_CULL_WALK", -1}, {"RT_NO_STAGE", 0}, {"RT_CULL_MINL", 3}, {"RT_FORCE_CAPPED", 0},
-    {"RT_STACK_LDS", 0}, {"RT_COMPACT", 1}, {"RT_REFILL_EIGHTHS", 0}, {"RT_TILE_SHAPE", 0}, {"RT_VERBOSE", 0}};
+    {"RT_STACK_LDS", 0}, {"RT_COMPACT", 1}, {"RT_REFILL_EIGHTHS", 0}, {"RT_TILE_SHAPE", 0}, {"RT_VERBOSE", 0}, {"RT_REORDER", 1}};
 std::once_flag g_dbg_once;
 void dbg_load_env() {
     std::call_once(g_dbg_once, [] {
@@ -124,6 +125,7 @@ constexpr uint32_t STREAM_CHUNK = 2048;         // chunk size when streaming thr
 constexpr uint32_t STACK_LDS_MAX = 12;          // quantised-node kernel: stack entries per lane in LDS, deeper ones in HBM
 constexpr uint32_t TRAVERSE_MIN_TRIS = 4;       // ... or above this many triangles (tools/crossover_tris.py: the LDS-tree walk wins from 8 triangles up)
 constexpr uint32_t RT_QNODES_MIN_PRIMS = 4096;   // from here up the traversal walks the 32-byte quantised nodes (tools/crossover_q.py)
+constexpr uint32_t REORDER_MIN_PRIMS = 64;      // from here up the primitive records are stored in the tree's depth-first leaf order
 constexpr uint32_t TRAVERSE_MIN_PRIMS = 32;     // above this many primitives the BVH-traversal engine is the default (measured with the LDS-resident tree: tools/crossover.py 0.91 at 16, 1.03 at 32, 1.10 at 64, 2.0 at 512; tools/heuristics_matrix.py at 48: +15...20 % on sparse fields, sheets and clusters, -3 % on dense overlap)
 
 }  // namespace
@@ -710,10 +712,87 @@ static void build_host_scene(const rt_sphere* sp, uint32_t ns, const rt_triangle
     hs.ns = ns;
     hs.nt = nt;
     hs.has_order = world_index != nullptr && ns + nt > 0;
-    if (hs.has_order) hs.world_rank.assign(world_index, world_index + ns + nt);
+    const uint32_t np = ns + nt;
+    // the reference's candidate-filter BVH (slave main.rs:60), built once per scene instead of per strip
+    std::vector<rtbvh::Box> boxes(np);
+    for (uint32_t i = 0; i < ns; i++) {              // Sphere::aabb, sphere.rs:65-72
+        const float c[3] = {sp[i].cx, sp[i].cy, sp[i].cz};
+        for (int a = 0; a < 3; a++) {
+            boxes[i].lo[a] = c[a] - sp[i].radius;
+            boxes[i].hi[a] = c[a] + sp[i].radius;
+        }
+    }
+    for (uint32_t i = 0; i < nt; i++) {              // Triangle::aabb, mesh.rs:46-96 (min_by / max_by order a,c,b)
+        for (int a = 0; a < 3; a++) {
+            const float va = tr[i].a[a], vb = tr[i].b[a], vc = tr[i].c[a];
+            const float m1 = va > vc ? vc : va;      // min_by(a, c): a unless a > c
+            boxes[ns + i].lo[a] = m1 > vb ? vb : m1;
+            const float x1 = va > vc ? va : vc;      // max_by(a, c): c unless a > c
+            boxes[ns + i].hi[a] = x1 > vb ? x1 : vb;
+        }
+    }
+    auto tb0 = std::chrono::steady_clock::now();
+    {
+        // BVH::build(&mut req.world) (slave main.rs:60) numbers the shapes by their position in `world`: start the build
+        // from the primitives in that order (rt_bvh.h); ties between equal distances then fall as in the reference
+        std::vector<uint32_t> order;
+        if (hs.has_order) {
+            order.resize(np);
+            for (uint32_t i = 0; i < np; i++) order[world_index[i]] = i;
+        }
+        hs.bvh = rtbvh::build(boxes, hs.has_order ? order.data() : nullptr);
+    }
+    rtbvh::FlatBVH& bvh = hs.bvh;
+    hs.bvh_build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - tb0).count();
+    hs.n_internal = (uint32_t)bvh.trav.size();        // before the placeholders below
+    if (bvh.nodes.empty()) bvh.nodes.push_back(rtbvh::FlatNode{{0, 0, 0}, 0xffffffffu, {0, 0, 0}, 0});
+    if (bvh.leaf_of.empty()) bvh.leaf_of.push_back(0);
+    if (bvh.trav.empty()) bvh.trav.push_back(rtbvh::TravNode{});
+    if (bvh.travq.empty()) bvh.travq.push_back(rtbvh::QNode{});
+    // ---- Storage order (round 3).  The records the kernels fetch per primitive — sphere (centre, radius), material, emission, triangle
+    // vertices — are laid out in the order in which the tree's depth-first walk meets the leaves, not in the caller's order: the
+    // primitives a ray (and the rays of a wave) touch are then neighbours in memory, four sphere records to a 64-byte line, instead of
+    // scattered over megabytes.  Only the library's INTERNAL primitive numbers change (spheres stay below n_sph, triangles above): leaf
+    // references, leaf ranks, the `big` list and the world positions are renumbered with them, and every rule that looks at a
+    // primitive's place in `world` (distance ties) goes through world_rank, which from here on always exists.
+    std::vector<rt_sphere> sp_store;
+    std::vector<rt_triangle> tr_store;
+    std::vector<uint32_t> wi_store(np ? np : 1, 0u);
+    for (uint32_t i = 0; i < np; i++) wi_store[i] = world_index ? world_index[i] : i;
+    if (np >= REORDER_MIN_PRIMS && dbg(DBG_REORDER) != 0) {
+        std::vector<uint32_t> old_of(np), new_of(np);
+        for (uint32_t i = 0; i < np; i++) old_of[i] = i;
+        std::stable_sort(old_of.begin(), old_of.begin() + ns, [&](uint32_t x, uint32_t y) { return bvh.leaf_of[x] < bvh.leaf_of[y]; });
+        std::stable_sort(old_of.begin() + ns, old_of.end(), [&](uint32_t x, uint32_t y) { return bvh.leaf_of[x] < bvh.leaf_of[y]; });
+        for (uint32_t i = 0; i < np; i++) new_of[old_of[i]] = i;
+        sp_store.resize(ns);
+        tr_store.resize(nt);
+        std::vector<rtbvh::Box> boxes2(np);
+        std::vector<uint32_t> leaf2(np), wi2(np);
+        for (uint32_t i = 0; i < np; i++) {
+            const uint32_t o = old_of[i];
+            if (i < ns) sp_store[i] = sp[o];
+            else tr_store[i - ns] = tr[o - ns];
+            boxes2[i] = boxes[o];
+            leaf2[i] = bvh.leaf_of[o];
+            wi2[i] = wi_store[o];
+        }
+        boxes.swap(boxes2);
+        bvh.leaf_of.swap(leaf2);
+        wi_store.swap(wi2);
+        auto remap = [&](uint32_t& ref) {
+            if (ref & rtbvh::LEAF_BIT) ref = rtbvh::LEAF_BIT | new_of[ref & ~rtbvh::LEAF_BIT];
+        };
+        for (rtbvh::TravNode& t : bvh.trav) { remap(t.left); remap(t.right); }
+        for (rtbvh::QNode& q : bvh.travq) { remap(q.left); remap(q.right); }
+        remap(bvh.root_ref);
+        sp = sp_store.data();
+        tr = tr_store.data();
+        hs.has_order = true;                 // (ties of the plain linear-scan semantics: by place in `world`, no longer by number)
+    }
+    if (hs.has_order) hs.world_rank.assign(wi_store.begin(), wi_store.begin() + np);
     else hs.world_rank.assign(1, 0u);
     hs.n_sph_pad = (ns + rtk::UNROLL - 1) / rtk::UNROLL * rtk::UNROLL;
-    const uint32_t np = ns + nt;
     std::vector<float4>& geom = hs.geom;
     std::vector<float4>& mat = hs.mat;
     std::vector<float>& emis = hs.emis;
@@ -779,48 +858,12 @@ static void build_host_scene(const rt_sphere* sp, uint32_t ns, const rt_triangle
             ok = std::isfinite(px[i].x) && std::isfinite(px[i].y) && std::isfinite(px[i].z) && std::isfinite(px[i].w);
         hs.expanded = ok;
     }
-    // the reference's candidate-filter BVH (slave main.rs:60), built once per scene instead of per strip
-    std::vector<rtbvh::Box> boxes(np);
-    for (uint32_t i = 0; i < ns; i++) {              // Sphere::aabb, sphere.rs:65-72
-        const float c[3] = {sp[i].cx, sp[i].cy, sp[i].cz};
-        for (int a = 0; a < 3; a++) {
-            boxes[i].lo[a] = c[a] - sp[i].radius;
-            boxes[i].hi[a] = c[a] + sp[i].radius;
-        }
-    }
-    for (uint32_t i = 0; i < nt; i++) {              // Triangle::aabb, mesh.rs:46-96 (min_by / max_by order a,c,b)
-        for (int a = 0; a < 3; a++) {
-            const float va = tr[i].a[a], vb = tr[i].b[a], vc = tr[i].c[a];
-            const float m1 = va > vc ? vc : va;      // min_by(a, c): a unless a > c
-            boxes[ns + i].lo[a] = m1 > vb ? vb : m1;
-            const float x1 = va > vc ? va : vc;      // max_by(a, c): c unless a > c
-            boxes[ns + i].hi[a] = x1 > vb ? x1 : vb;
-        }
-    }
     hs.tri_box.assign((size_t)nt * 2 + 1, make_float4(0.f, 0.f, 0.f, 0.f));
     for (uint32_t i = 0; i < nt; i++) {
         const rtbvh::Box& b = boxes[ns + i];
         hs.tri_box[2 * (size_t)i] = make_float4(b.lo[0], b.lo[1], b.lo[2], 0.f);
         hs.tri_box[2 * (size_t)i + 1] = make_float4(b.hi[0], b.hi[1], b.hi[2], 0.f);
     }
-    auto tb0 = std::chrono::steady_clock::now();
-    {
-        // BVH::build(&mut req.world) (slave main.rs:60) numbers the shapes by their position in `world`: start the build
-        // from the primitives in that order (rt_bvh.h); ties between equal distances then fall as in the reference
-        std::vector<uint32_t> order;
-        if (hs.has_order) {
-            order.resize(np);
-            for (uint32_t i = 0; i < np; i++) order[world_index[i]] = i;
-        }
-        hs.bvh = rtbvh::build(boxes, hs.has_order ? order.data() : nullptr);
-    }
-    rtbvh::FlatBVH& bvh = hs.bvh;
-    hs.bvh_build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - tb0).count();
-    hs.n_internal = (uint32_t)bvh.trav.size();        // before the placeholders below
-    if (bvh.nodes.empty()) bvh.nodes.push_back(rtbvh::FlatNode{{0, 0, 0}, 0xffffffffu, {0, 0, 0}, 0});
-    if (bvh.leaf_of.empty()) bvh.leaf_of.push_back(0);
-    if (bvh.trav.empty()) bvh.trav.push_back(rtbvh::TravNode{});
-    if (bvh.travq.empty()) bvh.travq.push_back(rtbvh::QNode{});
     {
         // worthwhile only if the grid step is small against the primitives (else the rounded boxes admit crowds of
         // false leaves): median primitive box edge >= 8 steps on every axis
