@@ -314,8 +314,8 @@ def main():
         segs, prim = float(c[0].item()), float(c[1].item())
 
     # PCIe-inclusive rate (never `value`): the same frame through the host-buffer entry point
-    # (rt_scene_render_tiles: kernel launches + D2H copies into pageable host memory, the copies of all but
-    # the last quarter of the strips overlapped with the last launch; d2h_ms = the exposed part), N = 1 only
+    # (rt_scene_render_tiles: kernel launches + D2H copies into pageable host memory; above 64 MiB the copies of all
+    # but the last quarter of the strips run under a second launch; d2h_ms = the exposed part), N = 1 only
     pcie = None
     if rank == 0 and world == 1 and not args.no_pcie:
         bufs, _, _ = scene.render_tiles(reqs)          # first pass touches the pages of the host buffers

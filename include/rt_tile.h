@@ -272,8 +272,8 @@ RT_API int rt_scene_collect(rt_scene* scene, rt_tile_stats* stats);
  * registers, allocates, uploads and spawns nothing.  rt_render_frame is the one-shot wrapper (create, set world, render
  * one frame, destroy).
  *
- * Strip assignment: strip k goes to devices[k % n_devices], all strips of a device in one launch, the downloads of all but
- * the last quarter of them under the last launch (default); with RT_FLAG_FRAME_QUEUE in req->flags the devices pull strips
+ * Strip assignment: strip k goes to devices[k % n_devices], all strips of a device in one launch (above 64 MiB of
+ * pixels per device: two, the last quarter of the strips running under the downloads of the rest) (default); with RT_FLAG_FRAME_QUEUE in req->flags the devices pull strips
  * one at a time, bottom of the frame first, two launches in flight per device.  The RGB8 strips are stitched by
  * division_no into out_rgb (H*W*3).  Same bytes either way.  No collective, no peer traffic: strips are independent.
  * req->division_no is ignored.  height % divisions must be 0 (the controller's from_vec(..).unwrap() panics otherwise). */

@@ -1259,7 +1259,10 @@ static int rt_scene_render_tiles_impl(rt_scene* sc, const rt_tile_request* rqs, 
     // before it (copy stream) run under it and only the last group's copies are exposed (d2h_ms = that exposed part).
     std::vector<std::pair<uint32_t, uint32_t>> groups;    // [first, count)
     {
-        const uint32_t tail = n >= 4 ? std::max<uint32_t>(1, n / 4) : 0;
+        // ... when the downloads are worth hiding: a second launch costs its own tail (half a millisecond at c3, one at c4), a
+        // frame's strips come down at about 50 GB/s, so below 64 MiB per call one launch and an exposed download are faster
+        // (c3, 24.9 MB: 9.3 instead of 9.6 ms per frame; c4's 99.5 MB keeps the split)
+        const uint32_t tail = (n >= 4 && (uint64_t)need * n > (64ull << 20)) ? std::max<uint32_t>(1, n / 4) : 0;
         for (uint32_t i0 = 0; i0 < n - tail; i0 += rtk::MAX_BATCH)
             groups.emplace_back(i0, std::min<uint32_t>(rtk::MAX_BATCH, n - tail - i0));
         for (uint32_t i0 = n - tail; i0 < n; i0 += rtk::MAX_BATCH)

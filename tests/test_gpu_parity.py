@@ -225,7 +225,20 @@ def test_render_frame_dispatcher(ndev):
         whole, _, st1 = sc.render_tile(rq1)
     assert np.array_equal(img.reshape(-1), whole)
     assert st.ray_segments == st1.ray_segments
-    assert st.n_launches == 2          # six strips, host buffers out: five in one launch, the last under their D2H copies
+    assert st.n_launches == 1          # a small frame: one launch, the download after it
+
+
+def test_large_frame_splits_its_batch_to_hide_the_download(ndev):
+    """Above 64 MiB of pixels per call the last quarter of the strips is a second launch that runs under the first one's D2H
+    copies; the frame is the same as the one the per-strip queue makes."""
+    sph, rq = _small("c2", 5760, 4320, spp=1, div=8)
+    rq.max_bounces = 2
+    a, st_a = rt.render_frame_native(rt.World(sph), rq)
+    rq_q = rq.copy()
+    rq_q.flags = _abi.RT_FLAG_FRAME_QUEUE
+    b, st_b = rt.render_frame_native(rt.World(sph), rq_q)
+    assert st_a.n_launches == 2 and st_b.n_launches == 8
+    assert np.array_equal(a, b) and st_a.ray_segments == st_b.ray_segments
 
 
 def test_batched_strips_one_launch(ndev, oracle):
@@ -418,7 +431,7 @@ def test_two_host_threads_on_one_device(ndev):
     a, st_a = rt.render_frame_native(rt.World(sph), rq, devices=[0, 0])
     b, st_b = rt.render_frame_native(rt.World(sph), rq, devices=[0])
     assert np.array_equal(a, b) and st_a.ray_segments == st_b.ray_segments
-    assert st_a.n_launches == 2 and st_b.n_launches == 2     # [0]: six strips = five + the last under their D2H
+    assert st_a.n_launches == 2 and st_b.n_launches == 1     # [0, 0]: three strips each; [0]: six strips in one launch
 
 
 def test_frame_dispatcher_strip_queue_and_pinning(ndev, oracle):
