@@ -289,7 +289,7 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     const size_t lt_lane = ((size_t)rtk::MAXL_LTREE + (size_t)(rq->max_bounces + 1) + (size_t)(sc->bvh_depth + 2)) * sizeof(uint16_t);
     if (traverse && ltree_env && !(rq->flags & RT_FLAG_NO_LDS_TREE) && sc->n_internal > 0 && n_prims <= 0x7fffu &&
         ((size_t)sc->n_internal + 2) * rtk::LNODE_DW < 0x8000u) {
-        const size_t fixed = ((size_t)sc->n_internal + 2) * (rtk::LNODE_DW * 4) + lt_lane * rtk::LTREE_BLOCK;   // + the DONE and MISS nodes
+        const size_t fixed = (((size_t)sc->n_internal + 2) * rtk::LNODE_DW + n_prims) * 4 + 16 + lt_lane * rtk::LTREE_BLOCK;   // + node DONE and the NaN field
         ltree_fits = fixed <= LDS_LIMIT;
     }
     // (Below the threshold a DENSE sphere scene whose tree does not fit LDS also takes the quantised nodes, for the culled
@@ -383,7 +383,7 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     const int bs = ltree ? rtk::LTREE_BLOCK : rtk::BLOCK;
     if (ltree) {
         // [nodes][leaf lists u16][path u16][stack u16]
-        size_t off = (((size_t)sc->n_internal + 2) * (rtk::LNODE_DW * 4) + 15) & ~(size_t)15;
+        size_t off = ((((size_t)sc->n_internal + 2) * rtk::LNODE_DW + n_prims) * 4 + 15) & ~(size_t)15;    // nodes, DONE, NaN field of n_prims + 19 dwords
         p.lds_cand_off = (uint32_t)off;
         off += (size_t)rtk::MAXL_LTREE * bs * sizeof(uint16_t);
         p.lds_path_off = (uint32_t)off;
@@ -430,7 +430,7 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
         p.q_rstep[i] = 1.0f / sc->grid.step[i];
     }
     p.root_ref = sc->root_ref;
-    if (ltree && (p.root_ref & rtk::LEAF_BIT)) p.root_ref = 0x8000u | (p.root_ref & 0x7fffu);
+    if (ltree) p.root_ref = (p.root_ref & rtk::LEAF_BIT) ? (0x8000u | (p.root_ref & 0x7fffu)) : rtk::lt_r0(sc->n_internal) + p.root_ref * (uint32_t)rtk::LNODE_DW;
     {
         // refill threshold: long walks (large scenes) want finished lanes replaced sooner, short walks amortise the
         // per-round shading / ray-generation code over more finished lanes (tools/variants_q.sh sweeps)

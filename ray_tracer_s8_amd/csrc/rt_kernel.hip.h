@@ -91,6 +91,8 @@ constexpr int TRAV_STACK = 64;   // traversal stack entries per lane (host falls
 constexpr int MAXL = RT_MAXL;    // leaf-candidate slots per lane in traversal mode (flushed when full)
 constexpr int MINL = RT_MINL;
 constexpr int MAXL_EXACT = 7;     // exact-node kernel: fixed (see the kernel)
+// bias of the LDS-tree kernel's node references: reference 0x8000 = the dword behind node DONE (see the staging code)
+__host__ __device__ inline uint32_t lt_r0(uint32_t n_internal) { return 0x8000u - (n_internal + 1u) * 19u; }
 constexpr int LNODE_DW = 19;      // LDS-tree kernel: dwords per staged node (see the staging code); odd, so that the
                                   // nodes start on all 32 banks
 #ifndef RT_MAXL_LTREE
@@ -587,17 +589,20 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
         // Stage the whole tree once per workgroup, 76 bytes per node, laid out for SIGN-SELECTED plane fetches: for
         // each axis and child the three dwords (lo, hi, lo), so that a two-dword read at dword offset s = (d.axis < 0)
         // returns (near, far) = (aabb[sign], aabb[1 - sign]) — literally ray.rs:175-176 — with no min / max / select in
-        // the step.  Dwords: l.x 0-2, r.x 3-5, l.y 6-8, r.y 9-11, l.z 12-14, r.z 15-17, 18 = left | right << 16 (16-bit
-        // references, leaf flag 0x8000; a node reference is the node's offset in dwords).  Two dummies follow the tree (see the
-        // step): entry n_internal is node DONE — its left box is all of space and its left child is DONE itself, its right box
-        // NaN — and entry n_internal + 1, the LAST one, is node MISS, NaN planes throughout.
+        // the step.  Dwords: l.x 0-2, r.x 3-5, l.y 6-8, r.y 9-11, l.z 12-14, r.z 15-17, 18 = left | right << 16.
+        // References are 16 bits: a leaf is 0x8000 | primitive, a node is LT_R0 + its offset in dwords, with the bias LT_R0
+        // chosen so that the dword after the last node has reference 0x8000.  After the tree comes node DONE (see the step: its
+        // left box is all of space and its left child DONE itself, its right box NaN) and then n_prims + 19 dwords of NaN:
+        // the address formed from a LEAF reference, base + 4 * (0x8000 + primitive), falls into that field, every 19-dword window of
+        // which is a node no ray enters — so a lane at a leaf gathers through the same address arithmetic as any other and
+        // fails both slab tests, without a clamp of the reference (round 3; before: one MISS node and min(reference, MISS)).
         float* ln = reinterpret_cast<float*>(lds_raw + p.lds_node_off);
-        for (uint32_t n = tid; n <= p.n_internal + 1u; n += BLOCK) {
+        const uint32_t r0 = lt_r0(p.n_internal);
+        for (uint32_t n = tid; n <= p.n_internal; n += BLOCK) {
             float* q = ln + LNODE_DW * n;
             if (n < p.n_internal) {
                 const float4 a0 = p.trav[4u * n], a1 = p.trav[4u * n + 1], a2 = p.trav[4u * n + 2], a3 = p.trav[4u * n + 3];
-                // a child reference is 0x8000 | primitive, or the child node's offset in dwords (= LNODE_DW * index)
-                auto ref16 = [](uint32_t r) { return (r & LEAF_BIT) ? (0x8000u | (r & 0x7fffu)) : r * (uint32_t)LNODE_DW; };
+                auto ref16 = [r0](uint32_t r) { return (r & LEAF_BIT) ? (0x8000u | (r & 0x7fffu)) : r0 + r * (uint32_t)LNODE_DW; };
                 q[0] = a0.x; q[1] = a1.x; q[2] = a0.x;   q[3] = a2.x; q[4] = a3.x; q[5] = a2.x;
                 q[6] = a0.y; q[7] = a1.y; q[8] = a0.y;   q[9] = a2.y; q[10] = a3.y; q[11] = a2.y;
                 q[12] = a0.z; q[13] = a1.z; q[14] = a0.z; q[15] = a2.z; q[16] = a3.z; q[17] = a2.z;
@@ -605,14 +610,16 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
             } else {
                 const float qn = __builtin_nanf(""), inf = __builtin_inff();
                 for (int i = 0; i < 18; i++) q[i] = qn;
-                if (n == p.n_internal)                        // DONE: the left box (lo, hi, lo) per axis = (-inf, +inf, -inf)
-                    for (int a = 0; a < 3; a++) { q[6 * a] = -inf; q[6 * a + 1] = inf; q[6 * a + 2] = -inf; }
-                q[18] = __uint_as_float((p.n_internal * (uint32_t)LNODE_DW) * 0x10001u);
+                for (int a = 0; a < 3; a++) { q[6 * a] = -inf; q[6 * a + 1] = inf; q[6 * a + 2] = -inf; }   // DONE: the left box (lo, hi, lo) per axis
+                q[18] = __uint_as_float((r0 + p.n_internal * (uint32_t)LNODE_DW) * 0x10001u);
             }
         }
+        float* nanf_ = ln + LNODE_DW * (p.n_internal + 1u);
+        for (uint32_t i = tid; i < p.n_sph + p.n_tri + (uint32_t)LNODE_DW; i += BLOCK) nanf_[i] = __builtin_nanf("");
         __syncthreads();
     }
-    const float* const lnodes = reinterpret_cast<const float*>(lds_raw + p.lds_node_off);
+    // (LTREE: biased by LT_R0 dwords, so that base + 4 * reference is the node's address; a 32-bit LDS address may wrap below zero and back)
+    const float* const lnodes = reinterpret_cast<const float*>(lds_raw + p.lds_node_off) - (LTREE ? (int)lt_r0(p.n_internal) : 0);
     const V3 corg = mk(p.org[0], p.org[1], p.org[2]);
     const V3 llc = mk(p.llc[0], p.llc[1], p.llc[2]);
     const V3 hor = mk(p.hor[0], p.hor[1], p.hor[2]);
@@ -673,7 +680,7 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
     uint16_t* lc16 = reinterpret_cast<uint16_t*>(lds_raw + p.lds_cand_off);     // LTREE: both 16-bit
     uint16_t* lstack16 = reinterpret_cast<uint16_t*>(lds_raw + p.lds_stack_off);
 
-    if (BFSTEP) lstack16[tid16] = (uint16_t)(p.n_internal * (uint32_t)LNODE_DW);  // stack slot 0: popping an empty stack yields DONE
+    if (BFSTEP) lstack16[tid16] = (uint16_t)(lt_r0(p.n_internal) + p.n_internal * (uint32_t)LNODE_DW);  // stack slot 0: popping an empty stack yields DONE
 
     auto drain_counters = [&]() {
         const unsigned long long ws = wave_sum(n_seg), wc = wave_sum(n_cand), wf = wave_sum(n_fall);
@@ -1144,12 +1151,11 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
             //     false and it pops.  MISS is the last node and every leaf reference (flag 0x8000) is larger than its offset,
             //     so the node to gather is min(reference, MISS): one instruction;
             //   * the right child is stored to stack[t_sp], the next free slot, pushed or not (t_sp += both);
-            //   * a leaf is stored to list[t_cnt], anything else to that same free stack slot (overwritten next);
+            //   * every reference is stored to list[t_cnt], the next free list slot, and only a leaf advances t_cnt;
             //   * the leaf list has room for a whole block of appends (checked between blocks): no fullness test.
             // The crate's literal slab test (a +-0 direction component, or RT_FLAG_FULL_CHAIN) is chosen per BLOCK of
             // steps for the whole wave: it is the reference's own test, valid for every lane.
-            const uint32_t DONE = p.n_internal * (uint32_t)LNODE_DW;            // node references are offsets in dwords
-            const uint32_t MISS = DONE + (uint32_t)LNODE_DW;
+            const uint32_t DONE = lt_r0(p.n_internal) + p.n_internal * (uint32_t)LNODE_DW;   // node references: LT_R0 + offset in dwords
             constexpr int STEPS = RT_STEPS_PER_CHECK_LTREE;
             static_assert(MAXL_LTREE > STEPS, "the leaf list must take a block of appends");
             // Inside a block the stack pointer and the list length are carried as LDS byte addresses (top_a: the lane's top
@@ -1165,14 +1171,17 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
             auto lds16 = [&](uint32_t a) -> lds_u16& { return *(lds_u16*)(uintptr_t)a; };
             auto step = [&](auto slow_tag) {
                 constexpr bool SLOW = decltype(slow_tag)::value;
-                const bool is_leaf = t_ref > 0x7fffu;
-                const uint32_t ni = min(t_ref, MISS);
+                // the leaf flag (bit 15) moved to the weight of one list slot: two fast-class instructions (shift right, and) where
+                // a compare and two selects were (tools/ubench/valu_classes: 2.7 against 4.4 cycles per wave-instruction)
+                static_assert(SLOT == 0x800u, "leaf flag 0x8000 >> 4 must be one slot");
+                const uint32_t leaf_slot = (t_ref >> 4) & SLOT;
+                const uint32_t ni = t_ref;                          // (a leaf's address lies in the NaN field behind the tree)
                 if (STATS) n_int += (ni < DONE) ? 1u : 0u;
                 const uint32_t top = (uint32_t)lds16(top_a);
                 WCOUNT(5);
                 LCOUNT(5);
-                // a leaf goes to the next list slot, anything else to the free stack slot (overwritten by the push below)
-                lds16((is_leaf ? cnt_m : top_a) + SLOT) = (uint16_t)t_ref;       // (the flush masks the leaf flag off)
+                // every reference goes to the next list slot; only a leaf moves the list's end past it
+                lds16(cnt_m + SLOT) = (uint16_t)t_ref;                           // (the flush masks the leaf flag off)
                 // Ray::intersects_aabb (ray.rs:174-194) on both child boxes; (near, far) planes fetched by sign
                 const float* __restrict__ nd = lnodes + ni;
                 const float* __restrict__ fx = nd + sgx;
@@ -1244,9 +1253,12 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
                 lds16(top_a + SLOT) = (uint16_t)cr;                // right subtree after the whole left subtree
                 const bool any = hl || hr;
                 t_ref = any ? (hl ? cl : cr) : top;
-                top_a = top_a + ((hl && hr) ? SLOT : 0u) - (any ? 0u : SLOT);
+                uint32_t delta = any ? 0u : 0u - SLOT;             // (two selects and a fast-class add; the sum of two selects was a v_add3)
+                delta = (hl && hr) ? SLOT : delta;
+                asm volatile("" : "+v"(delta));
+                top_a += delta;
                 if (SLOW) top_a = max(top_a, stack0_a);          // (DONE may pop here: see above)
-                cnt_m += is_leaf ? SLOT : 0u;
+                cnt_m += leaf_slot;
 #ifdef RT_PROBE_LT_LDS64
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 asm volatile("" ::"v"(e0_));

@@ -50,6 +50,22 @@ constexpr int ITER = 2048;
 #define I_PAIRV(n) "v_cmp_lt_f32 vcc, %" #n ", %8\n s_nop 1\n v_cndmask_b32 %" #n ", %" #n ", %9, vcc\n"
 #define I_PAIRS(n) "v_cmp_lt_f32 s[20:21], %" #n ", %8\n s_nop 1\n v_cndmask_b32 %" #n ", %" #n ", %9, s[20:21]\n"
 #define I_CNDV64(n) "v_cndmask_b32_e64 %" #n ", %" #n ", %8, vcc\n"
+#define I_LSHLADD(n) "v_lshl_add_u32 %" #n ", %" #n ", 2, %8\n"
+#define I_ADD3(n) "v_add3_u32 %" #n ", %" #n ", %8, %9\n"
+#define I_MAD24(n) "v_mad_u32_u24 %" #n ", %" #n ", 4, %8\n"
+#define I_MINU(n) "v_min_u32 %" #n ", %" #n ", %8\n"
+#define I_LSHR(n) "v_lshrrev_b32 %" #n ", 16, %" #n "\n"
+#define I_BFE(n) "v_bfe_u32 %" #n ", %" #n ", 3, 9\n"
+#define I_ANDOR(n) "v_and_or_b32 %" #n ", %" #n ", %8, %9\n"
+#define I_PKADD(n) "v_pk_add_f32 v[40:41], v[40:41], v[42:43]\n"
+#define I_PKMUL(n) "v_pk_mul_f32 v[40:41], v[40:41], v[42:43]\n"
+#define I_CMPLEU(n) "v_cmp_lt_u32 vcc, %" #n ", %8\n"
+#define I_SUBREV(n) "v_subrev_f32 %" #n ", %8, %" #n "\n"
+#define I_LSHLOR(n) "v_lshl_or_b32 %" #n ", %" #n ", 2, %8\n"
+#define I_PERM(n) "v_perm_b32 %" #n ", %" #n ", %8, %9\n"
+#define I_MAXI16(n) "v_pk_max_i16 %" #n ", %" #n ", %8\n"
+#define I_SUBU(n) "v_sub_u32 %" #n ", %" #n ", %8\n"
+#define I_MADF(n) "v_mad_f32 %" #n ", %" #n ", %8, %9\n"
 #define I_MAD64(n) "v_mad_u64_u32 v[40:41], s[20:21], %" #n ", %8, v[40:41]\n"
 
 template <int MODE>
@@ -95,6 +111,21 @@ __global__ __launch_bounds__(256) void k(float* out, float a, float b) {
         if (MODE == 35) R8(I_PAIRV);
         if (MODE == 36) R8(I_PAIRS);
         if (MODE == 37) R8(I_CNDV64);
+        if (MODE == 38) R8(I_LSHLADD);
+        if (MODE == 39) R8(I_ADD3);
+        if (MODE == 40) R8(I_MAD24);
+        if (MODE == 41) R8(I_MINU);
+        if (MODE == 42) R8(I_LSHR);
+        if (MODE == 43) R8(I_BFE);
+        if (MODE == 44) R8(I_ANDOR);
+        if (MODE == 45) asm volatile(I_PKADD(0) I_PKADD(0) I_PKADD(0) I_PKADD(0) I_PKADD(0) I_PKADD(0) I_PKADD(0) I_PKADD(0) ::: "v40", "v41", "v42", "v43");
+        if (MODE == 46) asm volatile(I_PKMUL(0) I_PKMUL(0) I_PKMUL(0) I_PKMUL(0) I_PKMUL(0) I_PKMUL(0) I_PKMUL(0) I_PKMUL(0) ::: "v40", "v41", "v42", "v43");
+        if (MODE == 47) R8(I_CMPLEU);
+        if (MODE == 48) R8(I_SUBREV);
+        if (MODE == 49) R8(I_LSHLOR);
+        if (MODE == 50) R8(I_PERM);
+        if (MODE == 51) R8(I_MAXI16);
+        if (MODE == 52) R8(I_SUBU);
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7;
 }
@@ -162,5 +193,21 @@ int main() {
     run<19>("v_cmp_lt_f32 vcc", d_out);
     run<20>("v_cmp_lt_f32 sgpr", d_out);
     run<24>("ds_bpermute_b32", d_out);
+    // round 3: the rest of the LDS-tree step's instruction kinds, and what could stand in for them
+    run<38>("v_lshl_add_u32", d_out);
+    run<49>("v_lshl_or_b32", d_out);
+    run<39>("v_add3_u32", d_out);
+    run<40>("v_mad_u32_u24", d_out);
+    run<41>("v_min_u32", d_out);
+    run<52>("v_sub_u32", d_out);
+    run<42>("v_lshrrev_b32", d_out);
+    run<43>("v_bfe_u32", d_out);
+    run<44>("v_and_or_b32", d_out);
+    run<50>("v_perm_b32", d_out);
+    run<51>("v_pk_max_i16", d_out);
+    run<45>("v_pk_add_f32 (dep chain)", d_out);
+    run<46>("v_pk_mul_f32 (dep chain)", d_out);
+    run<47>("v_cmp_lt_u32 vcc", d_out);
+    run<48>("v_subrev_f32", d_out);
     return 0;
 }
