@@ -95,6 +95,9 @@ constexpr int MAXL_EXACT = 7;     // exact-node kernel: fixed (see the kernel)
 __host__ __device__ inline uint32_t lt_r0(uint32_t n_internal) { return 0x8000u - (n_internal + 1u) * 19u; }
 constexpr int LNODE_DW = 19;      // LDS-tree kernel: dwords per staged node (see the staging code); odd, so that the
                                   // nodes start on all 32 banks
+#ifndef RT_LT_PARTIAL           // LDS-tree kernel: lanes with a pending candidate that make a partial root-test round (64: never)
+#define RT_LT_PARTIAL 40
+#endif
 #ifndef RT_MAXL_LTREE
 #define RT_MAXL_LTREE 12
 #endif
@@ -671,6 +674,7 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
     V3 td = mk(0, 0, 0);                     // linear engines: 2 * d of the current segment
     bool in_trav = false;
     uint32_t t_ref = 0, t_sp = 0, t_cnt = 0;
+    uint32_t t_head = 0;                      // LTREE: first list entry not root-tested yet (partial rounds, see the walk loop)
     V3 ig = mk(0, 0, 0), cq = mk(0, 0, 0);   // QNODES: the ray in grid units, t(q) = q * ig + cq
     bool qfin = false;                       // QNODES: this lane may use the quantised boxes
     float t_far = __builtin_inff();          // CULL: no primitive entered beyond this distance can beat the running hit
@@ -970,15 +974,7 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
             // exact root tests on them, first minimum wins (shapes/mod.rs:158-191).
             // Steps run until at most half of the wave's live lanes are still walking; the finished lanes are then
             // shaded / refilled while the stragglers keep their stack (LDS) and resume in the next round.
-            auto flush = [&]() {
-                if (BFSTEP) n_cand += t_cnt;                     // (the other steps count at the append)
-                // (Tried in round 3 and dropped on the LDS-tree kernel, tools/experiments/: striking the sure misses from the leaf
-                // lists first with the linear engines' conservative broad-phase test, r03_leaf_prefilter.patch, c3 14 560 -> 14 290;
-                // and the compacted root tests of the exact-node L2 kernel below in the LDS two list slots give back,
-                // r03_ltree_compacted_root_tests.patch: 2.7 % slower than its own per-lane flush, and the kernel that carries both
-                // flushes 12 % slower than the one that carries one — 109 instead of 105 VGPRs, 17 instead of 7 spilled SGPRs.)
-#pragma clang loop unroll(disable)
-                for (uint32_t i = 0; i < t_cnt; i++) {
+            auto root_test = [&](uint32_t i) {
                     LCOUNT(6);
                     const uint32_t prim = LTREE ? (uint32_t)lc16[i * BLOCK + tid16] & 0x7fffu
                                           : p.list16 ? (uint32_t)lc16[i * BLOCK + tid16] : lc32[i * BLOCK + tid];
@@ -1014,10 +1010,30 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
                                 consider<0>(h, (int)prim, o, d, t, aux, p.bvh_nodes, p.leaf_of);
                         }
                     }
-                }
+            };
+            auto flush = [&]() {
+                if (BFSTEP) n_cand += t_cnt - t_head;            // (the other steps count at the append)
+                // (Tried in round 3 and dropped on the LDS-tree kernel, tools/experiments/: striking the sure misses from the leaf
+                // lists first with the linear engines' conservative broad-phase test, r03_leaf_prefilter.patch, c3 14 560 -> 14 290;
+                // and the compacted root tests of the exact-node L2 kernel below in the LDS two list slots give back,
+                // r03_ltree_compacted_root_tests.patch: 2.7 % slower than its own per-lane flush, and the kernel that carries both
+                // flushes 12 % slower than the one that carries one — 109 instead of 105 VGPRs, 17 instead of 7 spilled SGPRs.
+                // Also: the next candidate's sphere record fetched while this one is tested, r03_ltree_flush_prefetch.patch, -1.8 %:
+                // the rounds do not wait for their records.)
+#pragma clang loop unroll(disable)
+                for (uint32_t i = BFSTEP ? t_head : 0u; i < t_cnt; i++) root_test(i);
                 t_cnt = 0;
+                if (BFSTEP) t_head = 0;
                 if (CULL && h.idx >= 0) t_far = far_bound(h.dist);
             };
+            // LTREE: one root test for every lane with a pending candidate, its oldest (list order kept: first minimum wins)
+            auto flush_one = [&]() {
+                n_cand++;
+                root_test(t_head);
+                t_head++;
+                if (t_head == t_cnt) t_head = t_cnt = 0;
+            };
+
             // ---- Compacted root tests (exact-node L2 kernel).  The per-lane flush above runs as many rounds as the longest
             // list of the wave, each at a handful of lanes (mesh workload: 17 rounds of 5.7 lanes per loop round, half of the
             // kernel's instructions).  Here the (lane, candidate) PAIRS of all flushing lanes are numbered consecutively and
@@ -1272,6 +1288,17 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
                 const uint32_t live = (uint32_t)__builtin_popcountll(__ballot(true));
                 if (walking == 0 || (walking * 8 <= live * p.refill_eighths && walking < live)) break;
                 if (in_trav && t_cnt > (uint32_t)(MAXL_LTREE - STEPS)) flush();   // room for a block of appends
+                // Partial rounds of root tests.  The flush after the walk runs as many rounds as the LONGEST list among the
+                // finished lanes, most of them at a handful of lanes (round 3 census: 4.0 rounds at 17.4 lanes per loop round,
+                // 18 % of the kernel's time for 1.34 candidates per query).  Here, between two blocks of steps, one candidate per
+                // lane — its oldest: list order is kept, the first minimum still wins — is tested as soon as RT_LT_PARTIAL lanes have
+                // one pending: 3.4 rounds at 21 lanes.
+                if (RT_LT_PARTIAL < 64) {
+                    const bool pend = t_cnt > t_head;
+                    if ((int)__builtin_popcountll(__ballot(pend)) >= RT_LT_PARTIAL) {
+                        if (pend) flush_one();
+                    }
+                }
                 const bool slow = __ballot(in_trav && !aux.finite) != 0;         // wave-uniform
                 if (in_trav) {
                     top_a = stack0_a + (t_sp - 1u) * SLOT;
