@@ -385,7 +385,12 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
         // [nodes][leaf lists u16][path u16][stack u16]
         size_t off = ((((size_t)sc->n_internal + 2) * rtk::LNODE_DW + n_prims) * 4 + 15) & ~(size_t)15;    // nodes, DONE, NaN field of n_prims + 19 dwords
         p.lds_cand_off = (uint32_t)off;
-        off += (size_t)rtk::MAXL_LTREE * bs * sizeof(uint16_t);
+        // leaf-list slots: MAXL_LTREE, and up to MAXL_LTREE_MAX where the tree leaves room (fewer flushes forced by a full list)
+        uint32_t lt_maxl = rtk::MAXL_LTREE;
+        while (lt_maxl < (uint32_t)rtk::MAXL_LTREE_MAX &&
+               off + ((size_t)(lt_maxl + 1) + p.depth + stack_need) * bs * sizeof(uint16_t) <= LDS_LIMIT) lt_maxl++;
+        p.maxl = lt_maxl;
+        off += (size_t)lt_maxl * bs * sizeof(uint16_t);
         p.lds_path_off = (uint32_t)off;
         off += (size_t)p.depth * bs * sizeof(uint16_t);
         p.lds_stack_off = (uint32_t)off;
@@ -1333,6 +1338,26 @@ extern "C" __attribute__((visibility("default"))) int rt_debug_read_counters(rt_
         std::lock_guard<std::mutex> lk(sc->mu);
         HIPCHK(hipSetDevice(sc->ctx->dev));
         HIPCHK(hipMemcpy(out, sc->d_counters + first, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        return RT_OK;
+    });
+}
+// debug: sqrt_rn of the traversal kernels against the compiler's IEEE sequence on every f32 bit pattern in [from, from + n);
+// *mismatches = patterns whose results differ.  Tests only; not part of rt_tile.h.
+extern "C" __attribute__((visibility("default"))) int rt_debug_sqrt_selftest(int device, uint32_t from, unsigned long long n,
+                                                                             unsigned long long* mismatches) {
+    return guarded([&]() -> int {
+        if (!mismatches || n > (1ull << 32) - from) return fail(RT_ERR_BAD_ARG, "sqrt self-test range");
+        HIPCHK(hipSetDevice(device));
+        unsigned long long* d_bad = nullptr;
+        HIPCHK(hipMalloc(&d_bad, sizeof(unsigned long long)));
+        hipError_t e = hipMemset(d_bad, 0, sizeof(unsigned long long));
+        if (e == hipSuccess) {
+            rtk::sqrt_selftest_launch(from, n, d_bad, 0);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpy(mismatches, d_bad, sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        (void)hipFree(d_bad);
+        if (e != hipSuccess) return fail(RT_ERR_HIP, hipGetErrorString(e));
         return RT_OK;
     });
 }

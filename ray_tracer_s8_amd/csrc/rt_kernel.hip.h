@@ -101,7 +101,8 @@ constexpr int LNODE_DW = 19;      // LDS-tree kernel: dwords per staged node (se
 #ifndef RT_MAXL_LTREE
 #define RT_MAXL_LTREE 12
 #endif
-constexpr int MAXL_LTREE = RT_MAXL_LTREE;     // LDS-tree kernel (16-bit entries): a block of RT_STEPS_PER_CHECK_LTREE appends always fits
+constexpr int MAXL_LTREE = RT_MAXL_LTREE;     // LDS-tree kernel (16-bit entries): a block of RT_STEPS_PER_CHECK_LTREE appends always fits;
+constexpr int MAXL_LTREE_MAX = 16;            // the host gives a tree that leaves room up to this many slots (KParams::maxl; c3 14: +0.5 %)
 constexpr uint32_t LEAF_BIT = 0x80000000u;
 // Output staging (north_star: "coalesced HBM stores of the tile"): a wave collects the RGB8 bytes of up to STAGE_SLOTS of
 // its 64x1 tiles in LDS and writes a finished tile as 48 whole dwords = three whole 64-byte lines.  Byte stores of
@@ -188,13 +189,58 @@ __device__ __forceinline__ V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b
 __device__ __forceinline__ V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 __device__ __forceinline__ V3 operator*(float s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
 __device__ __forceinline__ V3 operator*(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
-__device__ __forceinline__ V3 operator/(V3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
+// timing probes (never in a product build, wrong images): the IEEE square roots / divisions of the hot phases as the bare hardware
+// approximations, to price their correction and scaling sequences — -DRT_PROBE_FAST_SQRT, -DRT_PROBE_FAST_DIV
+// sqrtf, correctly rounded as IEEE 754 demands, for less than the compiler's sequence.  That sequence is v_sqrt_f32, two one-ulp
+// residual tests and, around them, a scaling of small operands and a class fix-up: 16 instructions, nine of them in the 4-cycle class
+// (tools/ubench/valu_classes).  Here: v_rsq_f32 and one coupled Newton step — seven fast-class instructions — which gives the
+// correctly rounded root for EVERY operand of magnitude 2^-96 ... below infinity (tools/ubench/ieee_cores.hip compares all 1.88e9 of
+// them with __builtin_sqrtf on the device; a negative operand gives NaN either way).  Lanes with any other operand (zero, tiny,
+// infinite, NaN) take the compiler's sequence behind a branch that is skipped when no lane of the wave needs it.
+// -DRT_IEEE_SQRT_PLAIN: the compiler's sequence everywhere (A/B runs).
+// NEG_OK: a negative operand of in-range magnitude stays on the fast path (NaN from either sequence; for results that only feed
+// comparisons — the discriminant of a miss); otherwise negative operands take the compiler's sequence too, whose NaN they keep.
+template <bool NEG_OK = false>
+__device__ __forceinline__ float sqrt_rn(float x) {
+#ifdef RT_IEEE_SQRT_PLAIN
+    return __builtin_sqrtf(x);
+#else
+    const float r = __builtin_amdgcn_rsqf(x);
+    float g = x * r, h = 0.5f * r;
+    const float e = __builtin_fmaf(-h, g, 0.5f);
+    g = __builtin_fmaf(g, e, g);
+    h = __builtin_fmaf(h, e, h);
+    const float dd = __builtin_fmaf(-g, g, x);
+    float y = __builtin_fmaf(dd, h, g);
+    const bool odd = ((__float_as_uint(x) & (NEG_OK ? 0x7fffffffu : 0xffffffffu)) - 0x0f800000u) >= (0x7f800000u - 0x0f800000u);
+    if (__ballot(odd)) {
+        if (odd) {
+            asm volatile("" : "+v"(x));        // (not to be speculated: without it the compiler computes both sequences and selects)
+            y = __builtin_sqrtf(x);
+        }
+    }
+    return y;
+#endif
+}
+#ifdef RT_PROBE_FAST_SQRT
+#define RT_SQRT(x_) __builtin_amdgcn_sqrtf(x_)
+#define RT_SQRT_NEG_OK(x_) __builtin_amdgcn_sqrtf(x_)
+#else
+#define RT_SQRT(x_) sqrt_rn(x_)
+#define RT_SQRT_NEG_OK(x_) sqrt_rn<true>(x_)
+#endif
+#ifdef RT_PROBE_FAST_DIV
+#define RT_DIV(a_, b_) ((a_) * __builtin_amdgcn_rcpf(b_))
+#else
+#define RT_DIV(a_, b_) ((a_) / (b_))
+#endif
+__device__ __forceinline__ V3 operator/(V3 a, float s) { return {RT_DIV(a.x, s), RT_DIV(a.y, s), RT_DIV(a.z, s)}; }
 // glam sse2 dot3 order: (x*x' + y*y') + z*z'
 __device__ __forceinline__ float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
-__device__ __forceinline__ float vlength(V3 a) { return __builtin_sqrtf(dot(a, a)); }
+__device__ __forceinline__ float vlength(V3 a) { return RT_SQRT(dot(a, a)); }
 __device__ __forceinline__ V3 normalize(V3 a) { return a / vlength(a); }   // glam normalize: divide
 __device__ __forceinline__ bool try_normalize(V3 a, V3& out) {            // glam try_normalize
-    float rcp = 1.0f / __builtin_sqrtf(dot(a, a));
+    float rcp = RT_DIV(1.0f, RT_SQRT(dot(a, a)));
     if (rcp > 0.0f && rcp < __builtin_inff()) {   // is_finite() && > 0
         out = a * rcp;
         return true;
@@ -257,16 +303,16 @@ __device__ __forceinline__ bool exact_sphere(V3 o, V3 td, V3 cen, float rr, floa
     // exactly those of the nested form; a NaN discriminant (non-finite operands) fails every comparison below, as there.
     const V3 oc = o - cen;
     const float b = dot(td, oc);
-    const float len = __builtin_sqrtf(dot(oc, oc));
+    const float len = RT_SQRT(dot(oc, oc));
     const float c = len * len - rr;
     const float disc = b * b - 4.0f * c;            // a1*a1 - _4*a2*a0, a2 = 1
-    const float sq = __builtin_sqrtf(disc);         // (NaN for a negative discriminant: that lane reports a miss below)
+    const float sq = RT_SQRT_NEG_OK(disc);         // (NaN for a negative discriminant: that lane reports a miss below)
     const bool bneg = b < 0.0f;
     const float same_sign = bneg ? -b + sq : -b - sq;
     const float diff_sign = bneg ? -b - sq : -b + sq;
     const float a0x2 = 2.0f * c;
     const bool big_s = __builtin_fabsf(same_sign) > 2.0f, big_d = __builtin_fabsf(diff_sign) > 2.0f;
-    const float q1 = a0x2 / same_sign, q2 = a0x2 / diff_sign, hs = same_sign / 2.0f, hd = diff_sign / 2.0f;
+    const float q1 = RT_DIV(a0x2, same_sign), q2 = RT_DIV(a0x2, diff_sign), hs = same_sign / 2.0f, hd = diff_sign / 2.0f;
     const float x1 = big_s ? q1 : hd;
     const float x2 = big_s ? (big_d ? q2 : hs) : hs;
     const bool one = disc == 0.0f;                  // Roots::One([-a1 / (2 a2)])
@@ -313,7 +359,7 @@ struct RayAux {
 __device__ __forceinline__ RayAux ray_aux(V3 d, bool full_chain) {
     RayAux a;
     a.full_chain = full_chain;
-    a.inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    a.inv = mk(RT_DIV(1.0f, d.x), RT_DIV(1.0f, d.y), RT_DIV(1.0f, d.z));
     a.sx = d.x < 0.0f;
     a.sy = d.y < 0.0f;
     a.sz = d.z < 0.0f;
@@ -883,7 +929,7 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
             LCOUNT(2);
             if (bounce) {
                 LCOUNT(3);
-                const float factor = 2.0f * __builtin_sqrtf(1.0f - sm);                // UnitSphere, main.rs:119
+                const float factor = 2.0f * RT_SQRT(1.0f - sm);                // UnitSphere, main.rs:119
                 const V3 us = mk(x1 * factor, x2 * factor, 1.0f - 2.0f * sm);
                 const V3 diffuse_dir = us + bn;
                 const V3 glossy_dir = d - (2.0f * dot(d, bn)) * bn;                    // main.rs:120-121
@@ -1287,7 +1333,7 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
                 const uint32_t walking = (uint32_t)__builtin_popcountll(__ballot(in_trav));
                 const uint32_t live = (uint32_t)__builtin_popcountll(__ballot(true));
                 if (walking == 0 || (walking * 8 <= live * p.refill_eighths && walking < live)) break;
-                if (in_trav && t_cnt > (uint32_t)(MAXL_LTREE - STEPS)) flush();   // room for a block of appends
+                if (in_trav && t_cnt > p.maxl - (uint32_t)STEPS) flush();          // room for a block of appends
                 // Partial rounds of root tests.  The flush after the walk runs as many rounds as the LONGEST list among the
                 // finished lanes, most of them at a handful of lanes (round 3 census: 4.0 rounds at 17.4 lanes per loop round,
                 // 18 % of the kernel's time for 1.34 candidates per query).  Here, between two blocks of steps, one candidate per
@@ -1852,6 +1898,7 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
 // The kernels are instantiated in rt_kernels_lin.hip / rt_kernels_trav.hip; the host side (rt_api.hip) gets them here.
 using KernelFn = void (*)(const KParams);
 KernelFn kernel_linear(bool streamed, bool expanded);
+void sqrt_selftest_launch(uint32_t from, unsigned long long n, unsigned long long* d_bad, hipStream_t st);   // rt_kernels_trav.hip
 KernelFn kernel_traverse(int variant, bool stats = false);   // 0: exact nodes, 1: quantised nodes, 2: quantised nodes with the capped LDS stack,
                                          // 3: exact nodes, whole tree resident in LDS (1024-thread workgroups)
                                          // 5: quantised nodes, nearer child first, distance culling (spheres only); 6: the same, capped LDS stack

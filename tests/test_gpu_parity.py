@@ -1015,3 +1015,18 @@ def test_grazing_rays_over_triangle_floors(ndev, oracle):
         engines.append(st.engine)
     assert engines[0] == 6 and engines[1] == 2
     assert st.ray_segments > rq.width * rq.height * rq.spp            # the floors are hit
+
+
+def test_sqrt_rn_is_the_ieee_square_root_on_every_f32(ndev):
+    """sqrt_rn (rt_kernel.hip.h: v_rsq_f32 + one coupled Newton step, the compiler's sequence for the operands outside its
+    domain) against __builtin_sqrtf on the device, all 2^32 bit patterns — negative, NaN, zero, subnormal and infinite ones
+    included — in both of its forms.  The oracle's sqrtf is the CPU's IEEE one; the committed golden vectors tie the two together."""
+    lib = _abi.load()
+    lib.rt_debug_sqrt_selftest.restype = C.c_int
+    lib.rt_debug_sqrt_selftest.argtypes = [C.c_int, C.c_uint32, C.c_ulonglong, C.POINTER(C.c_ulonglong)]
+    total = 0
+    for from_ in range(0, 1 << 32, 1 << 30):
+        bad = C.c_ulonglong(12345)
+        assert lib.rt_debug_sqrt_selftest(0, from_, 1 << 30, C.byref(bad)) == 0
+        total += bad.value
+    assert total == 0
