@@ -1030,3 +1030,39 @@ def test_sqrt_rn_is_the_ieee_square_root_on_every_f32(ndev):
         assert lib.rt_debug_sqrt_selftest(0, from_, 1 << 30, C.byref(bad)) == 0
         total += bad.value
     assert total == 0
+
+
+@pytest.mark.parametrize("n", [33, 65, 256, 700, 1024, 1090, 1160])
+def test_lds_tree_around_its_fit_boundary(ndev, oracle, n):
+    """The LDS-resident tree at sizes from just above the linear-scan rule to past what a CU's LDS holds: biased node references,
+    the NaN field behind the tree that a leaf's address falls into (the highest primitive index reads its last 19 dwords), leaf
+    lists of 12 ... 16 slots as the tree leaves room, partial rounds of root tests.  Whatever engine the host picks at a size, the
+    frame is the oracle's; up to the headline scene's size it is engine 4, and the L2 walk of the same scene gives the same bits."""
+    sph = scenes.rand1024(seed=0x1D5 + n, n=n)
+    rq = _abi.default_request(width=128, height=72, divisions=1, spp=3, max_bounces=7, seed=1000 + n)
+    st = _compare(oracle, rq, sph, flags=0)
+    if n <= 1024:
+        assert st.engine == 4
+    else:
+        assert st.engine in (2, 4, 6)
+    st2 = _compare(oracle, rq, sph, flags=_abi.RT_FLAG_NO_LDS_TREE)
+    assert st2.engine != 4 and st2.ray_segments == st.ray_segments
+
+
+def test_lds_tree_near_axis_rays_and_long_lists(ndev, oracle):
+    """Rays almost parallel to the z axis (a tiny field of view: huge inverse-direction components) through a pile of overlapping
+    spheres — leaf lists that fill up between blocks, so that the capacity flush and the partial rounds of root tests both run — in
+    the LDS-tree kernel."""
+    g = np.random.default_rng(77)
+    n = 400
+    sph = np.zeros(n, dtype=_abi.SPHERE_DTYPE)
+    sph["cx"], sph["cy"], sph["cz"] = g.uniform(-1.5, 1.5, n), g.uniform(-1.5, 1.5, n), g.uniform(-9.0, -6.0, n)
+    sph["radius"] = g.uniform(0.6, 1.4, n)                                  # a pile: every ray meets dozens of leaf boxes
+    sph["albedo_r"], sph["albedo_g"], sph["albedo_b"] = g.uniform(0.2, 0.9, n), g.uniform(0.2, 0.9, n), g.uniform(0.2, 0.9, n)
+    sph["roughness"] = np.where(g.uniform(size=n) < 0.5, 1.0, 0.0)          # mirrors keep directions axis-parallel after a bounce
+    sph["emission"] = np.where(g.uniform(size=n) < 0.05, 3.0, 0.0)
+    # a camera looking down -z with no aperture and a tiny field of view
+    rq = _abi.default_request(width=65, height=65, divisions=1, spp=2, max_bounces=6, aperture=0.0, fov=0.02, seed=5)
+    st = _compare(oracle, rq, sph, flags=0)
+    assert st.engine == 4
+    assert st.broad_candidates > 8 * st.ray_segments // 4                   # long lists: several candidates per segment
