@@ -126,6 +126,7 @@ constexpr uint32_t STACK_LDS_MAX = 12;          // quantised-node kernel: stack 
 constexpr uint32_t TRAVERSE_MIN_TRIS = 4;       // ... or above this many triangles (tools/crossover_tris.py: the LDS-tree walk wins from 8 triangles up)
 constexpr uint32_t RT_QNODES_MIN_PRIMS = 4096;   // from here up the traversal walks the 32-byte quantised nodes (tools/crossover_q.py)
 constexpr uint32_t REORDER_MIN_PRIMS = 64;      // from here up the primitive records are stored in the tree's depth-first leaf order
+constexpr float SMALL_TREE_MAX_DENSITY = 0.4f;      // sphere scenes of up to TRAVERSE_MIN_PRIMS spheres walk the tree below this box density (see `traverse`)
 constexpr uint32_t TRAVERSE_MIN_PRIMS = 32;     // above this many primitives the BVH-traversal engine is the default (measured with the LDS-resident tree: tools/crossover.py 0.91 at 16, 1.03 at 32, 1.10 at 64, 2.0 at 512; tools/heuristics_matrix.py at 48: +15...20 % on sparse fields, sheets and clusters, -3 % on dense overlap)
 
 }  // namespace
@@ -273,8 +274,13 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     const bool trav_ok = !(rq->flags & (RT_FLAG_EXACT_SCAN | RT_FLAG_NO_BVH_CULL | RT_FLAG_LINEAR_SCAN)) &&
                          sc->bvh_depth < (uint32_t)rtk::TRAV_STACK && n_prims > 0;   // LDS stack: (depth + 1) KiB per workgroup
     // (the linear engines test every triangle's box per segment: meshes switch to the tree much earlier)
+    // (... and so do SPARSE sphere scenes of any size from two spheres up: since round 3's work on the LDS-tree step the tree wins
+    // by 3...17 % wherever the culled walk's box density — the big spheres set aside — is below 0.4, and loses 1...15 % on piles of
+    // overlapping spheres at 1.1 and above; c2's room sits at 0.50 and stays with the scan it renders 2 % faster with.
+    // tools/small_scene_matrix.py: 33 scenes of 2...32 spheres)
+    const bool sparse_small = n_prims >= 2 && sc->n_tri == 0 && sc->cull_density < SMALL_TREE_MAX_DENSITY;
     const bool traverse = trav_ok && ((rq->flags & RT_FLAG_BVH_TRAVERSE) || n_prims > TRAVERSE_MIN_PRIMS ||
-                                      sc->n_tri > TRAVERSE_MIN_TRIS);
+                                      sc->n_tri > TRAVERSE_MIN_TRIS || sparse_small);
     // node format: from RT_QNODES_MIN_PRIMS primitives up the 32-byte quantised nodes (half the gather footprint, and an
     // LDS plan that keeps five workgroups per CU whatever the tree's depth): +14 % on sparse fields of every size, +17...29 %
     // on dense fields of 32 768+ spheres, within 2.5 % either way in between; below it the exact-node kernel's six

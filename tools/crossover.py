@@ -5,7 +5,7 @@ import numpy as np
 import ray_tracer_s8_amd as rt
 from ray_tracer_s8_amd import scenes, _abi
 rt.init()
-for n in (16, 32, 64, 128, 256, 512, 1024, 2048, 4096):
+for n in (16, 17, 20, 24, 28, 32, 48, 64, 128, 256, 512, 1024, 2048, 4096):
     sph = scenes.cornell16() if n == 16 else scenes.rand1024(n=n)
     rq = _abi.default_request(width=1920, height=1080, divisions=4, spp=4, max_bounces=8, seed=5)
     reqs = []
