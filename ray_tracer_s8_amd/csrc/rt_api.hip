@@ -126,6 +126,8 @@ constexpr uint32_t STACK_LDS_MAX = 12;          // quantised-node kernel: stack 
 constexpr uint32_t TRAVERSE_MIN_TRIS = 4;       // ... or above this many triangles (tools/crossover_tris.py: the LDS-tree walk wins from 8 triangles up)
 constexpr uint32_t RT_QNODES_MIN_PRIMS = 4096;   // from here up the traversal walks the 32-byte quantised nodes (tools/crossover_q.py)
 constexpr uint32_t REORDER_MIN_PRIMS = 64;      // from here up the primitive records are stored in the tree's depth-first leaf order
+constexpr uint32_t DENSE_LINEAR_MAX_PRIMS = 192;     // sphere scenes of up to this many spheres and at least ...
+constexpr float DENSE_LINEAR_MIN_DENSITY = 3.0f;     // ... this box density keep the linear scan (see `traverse`)
 constexpr float SMALL_TREE_MAX_DENSITY = 0.4f;      // sphere scenes of up to TRAVERSE_MIN_PRIMS spheres walk the tree below this box density (see `traverse`)
 constexpr uint32_t TRAVERSE_MIN_PRIMS = 32;     // above this many primitives the BVH-traversal engine is the default (measured with the LDS-resident tree: tools/crossover.py 0.91 at 16, 1.03 at 32, 1.10 at 64, 2.0 at 512; tools/heuristics_matrix.py at 48: +15...20 % on sparse fields, sheets and clusters, -3 % on dense overlap)
 
@@ -279,7 +281,11 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     // overlapping spheres at 1.1 and above; c2's room sits at 0.50 and stays with the scan it renders 2 % faster with.
     // tools/small_scene_matrix.py: 33 scenes of 2...32 spheres)
     const bool sparse_small = n_prims >= 2 && sc->n_tri == 0 && sc->cull_density < SMALL_TREE_MAX_DENSITY;
-    const bool traverse = trav_ok && ((rq->flags & RT_FLAG_BVH_TRAVERSE) || n_prims > TRAVERSE_MIN_PRIMS ||
+    // (... while PILES of overlapping spheres keep the scan well beyond the threshold: the LDS-tree walk has no distance culling, and
+    // at a box density of 3 and more a ray meets so many leaf boxes that the tree renders at 0.6...0.9 of the scan up to about 200
+    // spheres — tools/dense_matrix.py: 48...192 spheres at density 3.3...13; at 256 the scan's O(N) has caught up)
+    const bool dense_pile = sc->n_tri == 0 && n_prims <= DENSE_LINEAR_MAX_PRIMS && sc->cull_density >= DENSE_LINEAR_MIN_DENSITY;
+    const bool traverse = trav_ok && ((rq->flags & RT_FLAG_BVH_TRAVERSE) || (n_prims > TRAVERSE_MIN_PRIMS && !dense_pile) ||
                                       sc->n_tri > TRAVERSE_MIN_TRIS || sparse_small);
     // node format: from RT_QNODES_MIN_PRIMS primitives up the 32-byte quantised nodes (half the gather footprint, and an
     // LDS plan that keeps five workgroups per CU whatever the tree's depth): +14 % on sparse fields of every size, +17...29 %

@@ -49,17 +49,18 @@ def run(sph, depth):
         _, _, st = sc.render_tiles(reqs)
     return out, st.engine
 
-g = np.random.default_rng(7)
-room = scenes.cornell16()
-print(f"{'scene':18s} {'density':>8s}   depth 4: linear / tree (ratio)      depth 8: linear / tree (ratio)    default engine")
-for n in (2, 4, 8, 12, 16, 24, 32):
-    fams = [("field", field(n, g, [-24, -1, -48], [24, 10, -3], (0.15, 0.6))),
-            ("field no ground", field(n, g, [-6, -2, -16], [6, 4, -4], (0.3, 0.9), ground=False)),
-            ("dense", field(n, g, [-2, -1, -8], [2, 2, -4], (0.4, 0.9))),
-            ("sheet", field(n, g, [-8, 1.0, -20], [8, 1.05, -4], (0.1, 0.4)))]
-    if n <= 16:
-        fams.append(("room", room[:n]))
-    for name, s in fams:
-        (l4, t4), e = run(s, 4)
-        (l8, t8), _ = run(s, 8)
-        print(f"{name + ' ' + str(n):18s} {density(s):8.2f}   {l4:8.0f} / {t4:8.0f} ({t4 / l4:.2f})          {l8:8.0f} / {t8:8.0f} ({t8 / l8:.2f})    {e}", flush=True)
+if __name__ == "__main__":
+    g = np.random.default_rng(7)
+    room = scenes.cornell16()
+    print(f"{'scene':18s} {'density':>8s}   depth 4: linear / tree (ratio)      depth 8: linear / tree (ratio)    default engine")
+    for n in (2, 4, 8, 12, 16, 24, 32):
+        fams = [("field", field(n, g, [-24, -1, -48], [24, 10, -3], (0.15, 0.6))),
+                ("field no ground", field(n, g, [-6, -2, -16], [6, 4, -4], (0.3, 0.9), ground=False)),
+                ("dense", field(n, g, [-2, -1, -8], [2, 2, -4], (0.4, 0.9))),
+                ("sheet", field(n, g, [-8, 1.0, -20], [8, 1.05, -4], (0.1, 0.4)))]
+        if n <= 16:
+            fams.append(("room", room[:n]))
+        for name, s in fams:
+            (l4, t4), e = run(s, 4)
+            (l8, t8), _ = run(s, 8)
+            print(f"{name + ' ' + str(n):18s} {density(s):8.2f}   {l4:8.0f} / {t4:8.0f} ({t4 / l4:.2f})          {l8:8.0f} / {t8:8.0f} ({t8 / l8:.2f})    {e}", flush=True)
