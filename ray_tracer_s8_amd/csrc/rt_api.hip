@@ -284,7 +284,11 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     // (... while PILES of overlapping spheres keep the scan well beyond the threshold: the LDS-tree walk has no distance culling, and
     // at a box density of 3 and more a ray meets so many leaf boxes that the tree renders at 0.6...0.9 of the scan up to about 200
     // spheres — tools/dense_matrix.py: 48...192 spheres at density 3.3...13; at 256 the scan's O(N) has caught up)
-    const bool dense_pile = sc->n_tri == 0 && n_prims <= DENSE_LINEAR_MAX_PRIMS && sc->cull_density >= DENSE_LINEAR_MIN_DENSITY;
+    // (round 3, end, tools/dense_mid_matrix.py — three pile shapes of 128...1000 spheres: up to 384 spheres at densities 5...12 the scan
+    // still leads the tree by 18...30 %; beyond, and for still denser piles, the culled walk does: see dense_mid below)
+    const bool dense_pile = sc->n_tri == 0 && sc->cull_density >= DENSE_LINEAR_MIN_DENSITY &&
+                            (n_prims <= DENSE_LINEAR_MAX_PRIMS ||
+                             (n_prims <= 2 * DENSE_LINEAR_MAX_PRIMS && sc->cull_density >= 5.0f && sc->cull_density < 12.0f));
     const bool traverse = trav_ok && ((rq->flags & RT_FLAG_BVH_TRAVERSE) || (n_prims > TRAVERSE_MIN_PRIMS && !dense_pile) ||
                                       sc->n_tri > TRAVERSE_MIN_TRIS || sparse_small);
     // node format: from RT_QNODES_MIN_PRIMS primitives up the 32-byte quantised nodes (half the gather footprint, and an
@@ -307,8 +311,15 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     // (Below the threshold a DENSE sphere scene whose tree does not fit LDS also takes the quantised nodes, for the culled
     // walk below: tools/cull_matrix_small.py, 2 000...3 500 overlapping spheres 1.55...1.95 x over the exact-node walk, fields of
     // box density 1...2 0.87...0.98 — hence the higher bar of 2.5 here.)
-    const bool dense_mid = !ltree_fits && sc->cull_pays && sc->cull_density >= 2.5f && n_prims >= 512 &&
-                           !(rq->flags & RT_FLAG_NO_CULL_WALK);
+    // (... and a pile takes them even when its tree WOULD fit LDS: the LDS-tree walk has no distance culling, and from a box density
+    // of 7 at more than 384 spheres, or of 20 at more than 256, the culled walk through L2 leads it by 13...65 % — tools/dense_mid_matrix.py)
+    // (cull_pays asks for spheres small against the scene, which a pile's are not: against an engine without any culling the
+    // culled walk leads regardless, so here the bound only has to be valid)
+    const bool pile_fits = ltree_fits && sc->n_tri == 0 && std::isfinite(sc->r_slack) && !(rq->flags & RT_FLAG_NO_CULL_WALK) &&
+                           ((n_prims > 2 * DENSE_LINEAR_MAX_PRIMS && sc->cull_density >= 7.0f) ||
+                            (n_prims > 256 && sc->cull_density >= 20.0f));
+    const bool dense_mid = (sc->cull_pays && !(rq->flags & RT_FLAG_NO_CULL_WALK) && !ltree_fits && sc->cull_density >= 2.5f &&
+                            n_prims >= 512) || pile_fits;
     const bool qnodes = traverse && sc->quant_ok && !(rq->flags & RT_FLAG_EXACT_NODES) &&
                         ((rq->flags & RT_FLAG_QUANT_NODES) || (n_prims >= RT_QNODES_MIN_PRIMS && sc->n_tri <= sc->n_sph) || dense_mid);
     const bool ltree = ltree_fits && !qnodes;
@@ -319,7 +330,7 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     // (an explicit request flag wins over the process-level knob, the knob over the host rule)
     const int cull_env = dbg(DBG_CULL_WALK);
     const bool cull_want = (rq->flags & RT_FLAG_NO_CULL_WALK) ? false : (rq->flags & RT_FLAG_CULL_WALK) ? true
-                           : cull_env >= 0 ? cull_env != 0 : sc->cull_pays;
+                           : cull_env >= 0 ? cull_env != 0 : (sc->cull_pays || pile_fits);
     const bool cull = qnodes && cull_want && sc->n_tri == 0 && std::isfinite(sc->r_slack);
     // ... and over the exact nodes (kernel variant 7): scenes with triangles — the bound of cull_bound_tri — wherever the exact-node
     // L2 walk is the engine; default where the host heuristic says it pays (xcull_pays), forced by the same flags

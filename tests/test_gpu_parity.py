@@ -804,8 +804,10 @@ def test_culled_walk_odd_scenes(ndev, oracle, kind):
     # AABB with lo > hi, which the reference's sign-selected slab test rejects: the exact-node L2 walk once entered it.)
     c = _compare(oracle, rq, sph, flags=_abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_EXACT_NODES | _abi.RT_FLAG_NO_LDS_TREE)
     d = _compare(oracle, rq, sph, flags=_abi.RT_FLAG_LINEAR_SCAN)
-    e = _compare(oracle, rq, sph[:900] if kind != "odd_radii" else np.concatenate([sph[200:500], sph[900:1400]]), flags=0)
-    assert c.engine == 2 and d.engine in (0, 1) and e.engine == 4
+    part = sph[:900] if kind != "odd_radii" else np.concatenate([sph[200:500], sph[900:1400]])
+    e = _compare(oracle, rq, part, flags=_abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_EXACT_NODES)   # (a pile may go to the culled walk by default)
+    f = _compare(oracle, rq, part, flags=0)
+    assert c.engine == 2 and d.engine in (0, 1) and e.engine == 4 and f.engine in (4, 5)
 
 
 _EXTREME = {
@@ -1063,6 +1065,7 @@ def test_lds_tree_near_axis_rays_and_long_lists(ndev, oracle):
     sph["emission"] = np.where(g.uniform(size=n) < 0.05, 3.0, 0.0)
     # a camera looking down -z with no aperture and a tiny field of view
     rq = _abi.default_request(width=65, height=65, divisions=1, spp=2, max_bounces=6, aperture=0.0, fov=0.02, seed=5)
-    st = _compare(oracle, rq, sph, flags=0)
+    st = _compare(oracle, rq, sph, flags=_abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_EXACT_NODES)   # (by default a pile keeps off the LDS tree)
     assert st.engine == 4
     assert st.broad_candidates > 8 * st.ray_segments // 4                   # long lists: several candidates per segment
+    assert _compare(oracle, rq, sph, flags=0).engine != 4
