@@ -320,8 +320,13 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
                             (n_prims > 256 && sc->cull_density >= 20.0f));
     const bool dense_mid = (sc->cull_pays && !(rq->flags & RT_FLAG_NO_CULL_WALK) && !ltree_fits && sc->cull_density >= 2.5f &&
                             n_prims >= 512) || pile_fits;
+    // (... and so does a sphere FIELD between the LDS tree's limit and that threshold: at box densities of 0.15 and more the quantised
+    // walk leads the exact one by 17...24 % there — tools/qnodes_mid_matrix.py, 1200...4000 spheres; flat sheets of small spheres,
+    // 0.03...0.1, are the scenes the exact nodes win by up to 12 %, and clusters fail quant_ok)
+    const bool field_mid = !ltree_fits && sc->n_tri == 0 && n_prims < RT_QNODES_MIN_PRIMS && sc->cull_density >= 0.15f;
     const bool qnodes = traverse && sc->quant_ok && !(rq->flags & RT_FLAG_EXACT_NODES) &&
-                        ((rq->flags & RT_FLAG_QUANT_NODES) || (n_prims >= RT_QNODES_MIN_PRIMS && sc->n_tri <= sc->n_sph) || dense_mid);
+                        ((rq->flags & RT_FLAG_QUANT_NODES) || (n_prims >= RT_QNODES_MIN_PRIMS && sc->n_tri <= sc->n_sph) || dense_mid ||
+                         field_mid);
     const bool ltree = ltree_fits && !qnodes;
     // Culled walk (engine 5, kernel variant 5): the quantised walk nearer child first, subtrees beyond the running closest hit
     // skipped.  Spheres only (the bound is derived from the sphere root test's error terms).

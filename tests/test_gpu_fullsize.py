@@ -65,7 +65,7 @@ def test_c3_full_4k_bit_exact_and_filter_is_conservative(ndev, oracle):
     rgb_e, _, st_e = _frame_gpu(sph, rq, flags=128)
     assert st.engine == 4 and st_e.engine == 3
     assert np.array_equal(rgb_e, rgb) and st_e.ray_segments == st.ray_segments
-    rgb_g, _, st_g = _frame_gpu(sph, rq, flags=256)          # RT_FLAG_NO_LDS_TREE
+    rgb_g, _, st_g = _frame_gpu(sph, rq, flags=256 | 64)     # RT_FLAG_NO_LDS_TREE | RT_FLAG_EXACT_NODES
     assert st_g.engine == 2
     assert np.array_equal(rgb_g, rgb) and st_g.ray_segments == st.ray_segments
     # the two broad-phase forms of the linear engine (8-op expanded, 11-op oc) agree at full size

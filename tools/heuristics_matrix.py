@@ -50,7 +50,7 @@ F = _abi
 engines = [("linear", F.RT_FLAG_LINEAR_SCAN), ("L2 exact", F.RT_FLAG_BVH_TRAVERSE | F.RT_FLAG_EXACT_NODES | F.RT_FLAG_NO_LDS_TREE),
            ("L2 quant", F.RT_FLAG_BVH_TRAVERSE | F.RT_FLAG_QUANT_NODES), ("LDS tree", F.RT_FLAG_BVH_TRAVERSE | F.RT_FLAG_EXACT_NODES),
            ("default", 0)]
-names = {0: "linear", 1: "linear(streamed)", 2: "L2 exact", 3: "L2 quant", 4: "LDS tree"}
+names = {0: "linear", 1: "linear(streamed)", 2: "L2 exact", 3: "L2 quant", 4: "LDS tree", 5: "L2 quant culled", 6: "L2 exact culled"}
 print(f"{'scene':22s} " + " ".join(f"{e[0]:>10s}" for e in engines) + "   default picks / best")
 for name, sph, tri in cases:
     world = rt.World(sph if sph is not None else np.zeros(0, F.SPHERE_DTYPE), tri if tri is not None else np.zeros(0, F.TRIANGLE_DTYPE))
