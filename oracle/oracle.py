@@ -37,6 +37,8 @@ def load() -> C.CDLL:
         _lib.rt_oracle_hardware_threads.restype = C.c_int
         _lib.rt_oracle_pixel_seed.restype = C.c_uint64
         _lib.rt_oracle_pixel_seed.argtypes = [C.c_uint64, C.c_uint64]
+        _lib.rt_oracle_sample_seed.restype = C.c_uint64
+        _lib.rt_oracle_sample_seed.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]
         _lib.rt_oracle_find_roots_quadratic.restype = C.c_int
         _lib.rt_oracle_find_roots_quadratic.argtypes = [C.c_float, C.c_float, C.c_float, C.c_void_p]
     return _lib
@@ -54,8 +56,14 @@ def hardware_threads() -> int:
     return load().rt_oracle_hardware_threads()
 
 
-def render(req, spheres, triangles=None, backend: int = 0, nthreads: int = 0, want_f32: bool = False, world_index=None):
+RNG_SAMPLE, RNG_PIXEL, RNG_ROW = 0, 1, 2
+
+
+def render(req, spheres, triangles=None, backend: int = 0, nthreads: int = 0, want_f32: bool = False, world_index=None,
+           rng_mode: int = RNG_SAMPLE):
     """Render one strip.  `req` is any ctypes struct with rt_tile_request layout.
+    rng_mode: RNG_SAMPLE = the normative stream per (pixel, sample); RNG_PIXEL (one stream per pixel, rounds
+    1-3) and RNG_ROW (the reference's structure: one stream per row, S/main.rs:69-77) exist for the distribution test only.
     world_index: position of every sphere, then of every triangle, in the reference's `world: Vec<Object>` (None: spheres
     then triangles).  Returns (rgb uint8 [Hs*W*3], f32 or None, info dict)."""
     lib = load()
@@ -74,7 +82,7 @@ def render(req, spheres, triangles=None, backend: int = 0, nthreads: int = 0, wa
         raise ValueError("world_index: one entry per primitive")
     rc = lib.rt_oracle_render(C.byref(req), _p(sph), C.c_uint32(ns), _p(tri), C.c_uint32(nt), C.c_int(backend),
                               C.c_int(nthreads), _p(out), _p(outf) if want_f32 else None, C.byref(segs),
-                              C.byref(ms), C.byref(bms), _p(wi) if wi is not None else None)
+                              C.byref(ms), C.byref(bms), _p(wi) if wi is not None else None, C.c_int(rng_mode))
     if rc != 0:
         raise ValueError(f"rt_oracle_render: bad arguments ({rc})")
     return out, outf, {"ray_segments": segs.value, "render_ms": ms.value, "bvh_build_ms": bms.value}
@@ -95,6 +103,10 @@ def seed_from_u64(seed: int):
 
 def pixel_seed(job_seed: int, pix: int) -> int:
     return load().rt_oracle_pixel_seed(job_seed, pix)
+
+
+def sample_seed(job_seed: int, pix: int, spp: int, s: int) -> int:
+    return load().rt_oracle_sample_seed(job_seed, pix, spp, s)
 
 
 def draw(state4: np.ndarray, kind: int):

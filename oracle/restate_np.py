@@ -67,8 +67,12 @@ class SmallRng:
         return self.value0_1() * TWO + F(-1)
 
 
-def pixel_seed(job_seed, pixel_index):          # DESIGN.md "RNG"
+def pixel_seed(job_seed, pixel_index):          # rounds 1-3 (one stream per pixel); kept for the cross-check of the helper
     return SmallRng._mix((job_seed + (pixel_index + 1) * 0x9E3779B97F4A7C15) & M64)
+
+
+def sample_seed(job_seed, pixel_index, spp, sample):   # DESIGN.md "RNG": one stream per (pixel, sample)
+    return (job_seed + 4 * 0x9E3779B97F4A7C15 * (pixel_index * spp + sample)) & M64
 
 
 def unit_disc(rng):                             # rand_distr::UnitDisc
@@ -308,9 +312,9 @@ def render(req, spheres, triangles=None, world_index=None):
         yg = hs * req.division_no + yl
         yc = H - yg - 1
         for x in range(W):
-            rng = SmallRng.seed_from_u64(pixel_seed(req.seed, yg * W + x))
             pr, pg, pb = ZERO, ZERO, ZERO
-            for _ in range(req.spp):
+            for s in range(req.spp):
+                rng = SmallRng.seed_from_u64(sample_seed(req.seed, yg * W + x, req.spp, s))
                 o, d = cam.get_ray(x, yc, rng)
                 c = ray_color(world, o, d, req.max_bounces + 1, rng)
                 pr, pg, pb = pr + c[0], pg + c[1], pb + c[2]

@@ -41,7 +41,11 @@
 //   1 = SAH BVH candidate filter as in the reference (used as the timed CPU baseline
 //       so the CPU number has the reference's O(log N) asymptotics)
 // The reference's `SmallRng::from_entropy()` per row (S/main.rs:69) is replaced by the
-// deterministic per-pixel stream defined in DESIGN.md "RNG" (same in the HIP kernel).
+// deterministic stream per (pixel, sample) defined in DESIGN.md "RNG" (same in the HIP kernel):
+// rt_oracle_render's rng_mode 0.  Two more modes exist HERE ONLY, for the statistical comparison of
+// tests/test_rng_distribution.py: 1 = one stream per pixel spanning its samples (the definition of
+// rounds 1-3), 2 = the reference's own structure — one stream per ROW, consumed pixel after pixel,
+// sample after sample (S/main.rs:69-77) — seeded deterministically per row instead of from entropy.
 
 #include <atomic>
 #include <chrono>
@@ -123,10 +127,21 @@ inline Rng seed_from_u64(uint64_t state) {
     }
     return r;
 }
-// DESIGN.md "RNG": pixel p of a job uses SmallRng::seed_from_u64(h) with
-// h = the (p+1)-th SplitMix64 output of a generator seeded with the job seed.
+// DESIGN.md "RNG" (normative since round 4): sample s of pixel p of a job with S samples per pixel draws from
+//   SmallRng::seed_from_u64(job_seed + 4 * PHI * (p * S + s))      (wrapping u64 arithmetic)
+// i.e. the SplitMix64 sequence of the job seed is cut into consecutive blocks of four outputs and block p * S + s
+// is that sample's xoshiro256++ state (seed_from_u64 fills the state with the next four SplitMix64 outputs).
+inline uint64_t sample_seed(uint64_t job_seed, uint64_t pixel_index, uint64_t spp, uint64_t sample) {
+    return job_seed + 4ull * PHI * (pixel_index * spp + sample);
+}
+// rng_mode 1 (rounds 1-3, comparison only): pixel p uses SmallRng::seed_from_u64(h) with
+// h = the (p+1)-th SplitMix64 output of a generator seeded with the job seed; the stream spans the pixel's samples.
 inline uint64_t pixel_seed(uint64_t job_seed, uint64_t pixel_index) {
     return splitmix_mix(job_seed + (pixel_index + 1) * PHI);
+}
+// rng_mode 2 (comparison only): the reference's one stream per row, seeded from (job seed, global row) instead of entropy
+inline uint64_t row_seed(uint64_t job_seed, uint64_t global_row) {
+    return splitmix_mix(~job_seed + (global_row + 1) * PHI);
 }
 // [1,2) float from the top 23 bits, minus 1  (rand UniformFloat / Standard mantissa trick)
 inline float u01_from_u32(uint32_t v) {
@@ -668,6 +683,7 @@ struct Job {
     Camera cam;
     rt_tile_request req;
     uint32_t hs;
+    int rng_mode;   // 0: one stream per (pixel, sample) — normative; 1: per pixel; 2: per row (the reference's structure)
 };
 
 // pixels [x_begin, x_end) of strip row yl
@@ -677,11 +693,13 @@ void render_span(const Job& job, uint32_t yl, uint32_t x_begin, uint32_t x_end, 
     Ctx cx{&job.sc, 0};
     const uint32_t W = rq.width, H = rq.height;
     uint32_t yg = job.hs * rq.division_no + yl;  // :66-68
+    Rng rng = seed_from_u64(row_seed(rq.seed, yg));   // :69 (rng_mode 2: the caller hands over whole rows)
     for (uint32_t x = x_begin; x < x_end; x++) {
         uint32_t yc = H - yg - 1;  // :71
-        Rng rng = seed_from_u64(pixel_seed(rq.seed, (uint64_t)yg * W + x));
+        if (job.rng_mode == 1) rng = seed_from_u64(pixel_seed(rq.seed, (uint64_t)yg * W + x));
         Color pix{0.f, 0.f, 0.f};
         for (uint32_t s = 0; s < rq.spp; s++) {
+            if (job.rng_mode == 0) rng = seed_from_u64(sample_seed(rq.seed, (uint64_t)yg * W + x, rq.spp, s));
             Ray r = camera_get_ray(job.cam, x, yc, rng);
             pix = pix + ray_color(cx, r, rq.max_bounces + 1, rng);
         }
@@ -733,7 +751,8 @@ extern "C" {
 
 // Render one strip.  backend: 0 linear, 1 bvh.  nthreads <= 0: hardware_concurrency.
 // Rows are distributed dynamically over threads (rayon-like); results do not depend on
-// nthreads because every pixel owns its RNG stream.
+// nthreads because every sample (rng_mode 1: pixel, 2: row) owns its RNG stream.
+// rng_mode: 0 = the normative stream per (pixel, sample); 1, 2: see the file header (statistics only).
 // out_f32 may be NULL.  *bvh_build_ms (may be NULL) receives the BVH build time.
 // world_index (may be NULL): include/rt_tile.h "the world's order".
 __attribute__((visibility("default"))) int rt_oracle_render(const rt_tile_request* rq, const rt_sphere* sp,
@@ -741,9 +760,9 @@ __attribute__((visibility("default"))) int rt_oracle_render(const rt_tile_reques
                                                             int backend, int nthreads, uint8_t* out_rgb,
                                                             float* out_f32, uint64_t* ray_segments,
                                                             double* render_ms, double* bvh_build_ms,
-                                                            const uint32_t* world_index) {
+                                                            const uint32_t* world_index, int rng_mode) {
     if (!rq || !out_rgb || rq->width == 0 || rq->height == 0 || rq->divisions == 0 ||
-        rq->division_no >= rq->divisions || rq->spp == 0)
+        rq->division_no >= rq->divisions || rq->spp == 0 || rng_mode < 0 || rng_mode > 2)
         return -1;
     if (world_index) {
         std::vector<char> seen((size_t)ns + nt, 0);
@@ -761,11 +780,13 @@ __attribute__((visibility("default"))) int rt_oracle_render(const rt_tile_reques
     job.cam = make_camera(rq);
     job.req = *rq;
     job.hs = rq->height / rq->divisions;
+    job.rng_mode = rng_mode;
     int nt_ = nthreads > 0 ? nthreads : (int)std::thread::hardware_concurrency();
     if (nt_ < 1) nt_ = 1;
     // work unit = 64 consecutive pixels of a row (the reference's rayon unit is a whole row,
     // main.rs:62-65; a finer unit only changes scheduling, every pixel owns its RNG stream)
-    const uint32_t SPAN = 64;
+    // (rng_mode 2: the stream runs along the row, so the unit is the reference's: a whole row)
+    const uint32_t SPAN = rng_mode == 2 ? rq->width : 64;
     const uint32_t spans_per_row = (rq->width + SPAN - 1) / SPAN;
     const uint64_t n_units = (uint64_t)spans_per_row * job.hs;
     if ((uint64_t)nt_ > n_units) nt_ = n_units ? (int)n_units : 1;
@@ -817,6 +838,9 @@ __attribute__((visibility("default"))) void rt_oracle_seed_from_u64(uint64_t see
 }
 __attribute__((visibility("default"))) uint64_t rt_oracle_pixel_seed(uint64_t job_seed, uint64_t pix) {
     return pixel_seed(job_seed, pix);
+}
+__attribute__((visibility("default"))) uint64_t rt_oracle_sample_seed(uint64_t job_seed, uint64_t pix, uint64_t spp, uint64_t s) {
+    return sample_seed(job_seed, pix, spp, s);
 }
 // draws: kind 0 = gen_range(0..1), 1 = Uniform(-1,1), 2 = UnitDisc (2 floats), 3 = UnitSphere (3 floats)
 __attribute__((visibility("default"))) void rt_oracle_draw(uint64_t* state4, int kind, float* out) {
