@@ -56,6 +56,7 @@ typedef enum rt_status {
 } rt_status;
 
 #define RT_MAX_BOUNCES 62u      /* path stack depth limit (reference literal is 10)           */
+#define RT_MAX_SPP 4096u        /* samples per pixel limit (reference literal is 100)         */
 #define RT_MAX_PRIMITIVES 0x3ffffffu /* spheres + triangles per scene: the kernels address nodes, geometry and
                                    materials with 32-bit byte offsets (64 B per tree node)    */
 

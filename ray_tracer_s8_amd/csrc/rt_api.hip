@@ -87,27 +87,27 @@ enum DebugKnob {
     DBG_LDS_TREE = 0,      // RT_LDS_TREE        0: never the LDS-resident tree engine                      (default 1)
     DBG_CULL_WALK,         // RT_CULL_WALK       0 / 1: culled walk off / on wherever it is valid; -1: host rule (default -1)
     DBG_NO_STAGE,          // RT_NO_STAGE        1: no LDS output staging                                   (default 0)
-    DBG_CULL_MINL,         // RT_CULL_MINL       leaf-list slots the culled walk keeps when it trades them for staging (3)
+    DBG_SLOTS,             // RT_SLOTS           sample units: pixel slots per wave (<= 32); 0: host rule                  (default 0)
     DBG_FORCE_CAPPED,      // RT_FORCE_CAPPED    1: quantised walks take the capped-stack kernel             (default 0)
     DBG_STACK_LDS,         // RT_STACK_LDS       capped-stack kernel: stack entries per lane in LDS; 0: STACK_LDS_MAX
     DBG_COMPACT,           // RT_COMPACT         0: per-lane root tests in the exact-node L2 kernel          (default 1)
     DBG_REFILL_EIGHTHS,    // RT_REFILL_EIGHTHS  refill threshold of the walks; 0: host rule
-    DBG_TILE_8X8,          // RT_TILE_SHAPE=8x8  square tiles                                               (default 0)
+    DBG_COMMIT_SLOTS,      // RT_COMMIT_SLOTS    sample units: complete slots a commit waits for; 0: host rule             (default 0)
     DBG_VERBOSE,           // RT_VERBOSE         engine / LDS plan of every launch on stderr                 (default 0)
     DBG_REORDER,           // RT_REORDER         0: primitive records stay in the caller's order (A/B)          (default 1)
     DBG_N
 };
 std::atomic<int> g_dbg[DBG_N];
 const struct { const char* env; int def; } g_dbg_spec[DBG_N] = {
-    {"RT_LDS_TREE", 1}, {"RT_CULL_WALK", -1}, {"RT_NO_STAGE", 0}, {"RT_CULL_MINL", 3}, {"RT_FORCE_CAPPED", 0},
-    {"RT_STACK_LDS", 0}, {"RT_COMPACT", 1}, {"RT_REFILL_EIGHTHS", 0}, {"RT_TILE_SHAPE", 0}, {"RT_VERBOSE", 0}, {"RT_REORDER", 1}};
+    {"RT_LDS_TREE", 1}, {"RT_CULL_WALK", -1}, {"RT_NO_STAGE", 0}, {"RT_SLOTS", 0}, {"RT_FORCE_CAPPED", 0},
+    {"RT_STACK_LDS", 0}, {"RT_COMPACT", 1}, {"RT_REFILL_EIGHTHS", 0}, {"RT_COMMIT_SLOTS", 0}, {"RT_VERBOSE", 0}, {"RT_REORDER", 1}};
 std::once_flag g_dbg_once;
 void dbg_load_env() {
     std::call_once(g_dbg_once, [] {
         for (int k = 0; k < DBG_N; k++) {
             const char* e = getenv(g_dbg_spec[k].env);
             int v = g_dbg_spec[k].def;
-            if (e) v = k == DBG_TILE_8X8 ? (strcmp(e, "8x8") == 0) : k == DBG_VERBOSE ? 1 : atoi(e);
+            if (e) v = k == DBG_VERBOSE ? 1 : atoi(e);
             g_dbg[k].store(v, std::memory_order_relaxed);
         }
     });
@@ -119,7 +119,8 @@ bool g_init = false;
 std::vector<DeviceCtx*> g_ctx;
 std::atomic<int> g_live_scenes{0};   // rt_shutdown is refused while any scene is alive (scenes point at their DeviceCtx)
 
-constexpr size_t LDS_LIMIT = 160 * 1024 - 1024;   // dynamic LDS budget; 1 KiB left for the kernels' static LDS
+constexpr size_t LDS_LIMIT = 160 * 1024 - 3072;   // dynamic LDS budget; 3 KiB left for the kernels' static LDS (the queue words and
+                                                  // one rtk::WaveQ per wave: 16 + 16 x 160 bytes in the 1024-thread kernel)
 constexpr uint32_t RESIDENT_MAX = rtk::CHUNK;   // spheres kept wholly in LDS
 constexpr uint32_t STREAM_CHUNK = 2048;         // chunk size when streaming through LDS
 constexpr uint32_t STACK_LDS_MAX = 12;          // quantised-node kernel: stack entries per lane in LDS, deeper ones in HBM
@@ -170,6 +171,18 @@ struct rt_scene {
     bool has_order = false;
     float bvh_build_ms = 0.f;
     unsigned long long* d_counters = nullptr;   // [0..2] stats, [4 + slot] tile queues
+    // Sample-unit rings (rt_kernel.hip.h "Sample units"): scratch of one launch, [waves][slots][16 B].  Launches on ONE stream
+    // follow each other, so a ring belongs to the stream that used it last; a launch on another stream that has to share it
+    // (more streams than rings) waits for that launch's end first.
+    struct Ring {
+        float* d = nullptr;
+        size_t bytes = 0;
+        hipStream_t last = nullptr;
+        hipEvent_t done = nullptr;          // end of the last launch that used it
+        uint64_t stamp = 0;
+    };
+    Ring rings[4];
+    uint64_t ring_clock = 0;
     // staging for the host-buffer entry point (grown on demand)
     uint8_t* d_out = nullptr;
     size_t d_out_cap = 0;
@@ -192,6 +205,7 @@ int check_request(const rt_tile_request* rq) {
     if (rq->division_no >= rq->divisions) return fail(RT_ERR_BAD_ARG, "division_no >= divisions");
     if (rq->height / rq->divisions == 0) return fail(RT_ERR_BAD_ARG, "height / divisions == 0 rows");
     if (rq->max_bounces > RT_MAX_BOUNCES) return fail(RT_ERR_LIMIT, "max_bounces > RT_MAX_BOUNCES");
+    if (rq->spp > RT_MAX_SPP) return fail(RT_ERR_LIMIT, "spp > RT_MAX_SPP");
     if (rq->reserved != 0) return fail(RT_ERR_BAD_ARG, "reserved must be 0");
     if ((uint64_t)rq->width * rq->height > 0x7fffffffull) return fail(RT_ERR_LIMIT, "image too large");
     return RT_OK;
@@ -358,35 +372,21 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     // does not fit takes the capped-stack kernel.
     // stack slots per lane: up to bvh_depth pending right children (+ 1 spare); the LDS-tree kernel's branch-free step
     // adds the DONE sentinel in slot 0 and needs the free slot its unconditional stores land in
-    // output staging (rtk::STAGE_SLOTS tiles per wave): wherever the LDS plan has room for it
+    // output staging (one tile per wave): wherever the LDS plan has room for it
     const bool want_stage = dbg(DBG_NO_STAGE) == 0 && ((traverse && !ltree) || streamed);     // the kernels it is compiled into (see there)
     const bool list16 = traverse && !ltree && n_prims <= 65536u;          // 16-bit leaf-list entries: half the LDS
-    size_t stage_bytes_wg = (size_t)rtk::STAGE_BYTES * ((ltree ? rtk::LTREE_BLOCK : rtk::BLOCK) / 64);
-    uint32_t stage_slots = rtk::STAGE_SLOTS;
+    const size_t stage_bytes_wg = (size_t)rtk::STAGE_TILES * rtk::STAGE_TILE_BYTES * ((ltree ? rtk::LTREE_BLOCK : rtk::BLOCK) / 64);
     const uint32_t stack_capped = sc->bvh_depth + 1;
     const uint32_t stack_need = sc->bvh_depth + (ltree ? 2u : 1u);
     uint32_t maxl = qnodes ? (uint32_t)rtk::MAXL : (uint32_t)rtk::MAXL_EXACT, stack_lds = stack_need;
     bool capped = false;
     if (traverse && qnodes) {
-        const size_t per_wg = (160u * 1024u - 4096u) / 5u - 256u;     // 4 KiB of slack, 256 B static LDS
+        const size_t per_wg = (160u * 1024u - 4096u) / 5u - 512u;     // 4 KiB of slack, 464 B static LDS
         const size_t slot = (size_t)rtk::BLOCK * (list16 ? sizeof(uint16_t) : sizeof(uint32_t));
-        // the culled walk needs short leaf lists only (its candidates are few and tested early), so it trades list slots for
-        // staging slots: every tile that finds no free staging slot is stored byte by byte and written back many times over
-        // (c5 WRITE_SIZE: 3 slots 1.42 x the frame)
-        const uint32_t cull_minl = (uint32_t)std::max(1, dbg(DBG_CULL_MINL));
-        if (want_stage && cull) {
-            const size_t base = path_bytes + (size_t)stack_need * rtk::BLOCK * sizeof(uint32_t);
-            for (uint32_t s_ = rtk::STAGE_SLOTS_MAX; s_ > rtk::STAGE_SLOTS; s_--)
-                if (base + (size_t)s_ * rtk::STAGE_TILE_BYTES * (rtk::BLOCK / 64) + (size_t)cull_minl * slot <= per_wg) {
-                    stage_slots = s_;
-                    stage_bytes_wg = (size_t)s_ * rtk::STAGE_TILE_BYTES * (rtk::BLOCK / 64);
-                    break;
-                }
-        }
         const size_t fixed = path_bytes + (size_t)stack_need * rtk::BLOCK * sizeof(uint32_t) + (want_stage ? stage_bytes_wg : 0);
         // (DBG_FORCE_CAPPED / DBG_STACK_LDS: tests drive the capped-stack kernel with small trees)
         const bool force_capped = dbg(DBG_FORCE_CAPPED) != 0;
-        if (!force_capped && fixed + (size_t)(stage_slots > rtk::STAGE_SLOTS ? cull_minl : (uint32_t)rtk::MINL) * slot <= per_wg) {
+        if (!force_capped && fixed + (size_t)rtk::MINL * slot <= per_wg) {
             maxl = (uint32_t)std::min<size_t>((size_t)rtk::MAXL, (per_wg - fixed) / slot);
         } else {
             const uint32_t cap = dbg(DBG_STACK_LDS) > 0 ? (uint32_t)dbg(DBG_STACK_LDS) : STACK_LDS_MAX;
@@ -433,7 +433,6 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
         p.lds_cmp_off = (uint32_t)lds;
         lds += 1024u * (rtk::BLOCK / 64);
     }
-    p.stage_slots = stage_slots;
     p.lds_stage_off = 0xffffffffu;
     if (want_stage && lds + stage_bytes_wg <= LDS_LIMIT) {
         lds = (lds + 15) & ~(size_t)15;
@@ -473,14 +472,28 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     p.leaf_of = sc->d_leaf_of;
     p.world_rank = sc->has_order ? sc->d_world_rank : nullptr;
     p.n_strips = n;
-    // Tile shape: 64x1 keeps each tile row on whole 64-byte lines of the RGB8 strip (64 px * 3 B = 3 lines),
+    // Tile shape: 64x1 keeps each tile on whole 64-byte lines of the RGB8 strip (64 px * 3 B = 3 lines),
     // so one CU / one XCD L2 writes every byte of a line; 8x8 tiles split lines across XCDs and doubled the
-    // HBM write traffic (profiles/).  RT_TILE_SHAPE=8x8 restores square tiles for A/B runs.
-    const bool square = dbg(DBG_TILE_8X8) != 0;
-    p.tile_wlog2 = (!square && p.W >= 64) ? 6u : 3u;
-    const uint32_t tw = 1u << p.tile_wlog2, th = 64u >> p.tile_wlog2;
-    p.tiles_x = (p.W + tw - 1) / tw;
-    p.tiles_per_strip = p.tiles_x * ((p.Hs + th - 1) / th);
+    // HBM write traffic (profiles/r01_*).
+    p.tiles_x = (p.W + 63u) / 64u;
+    p.tiles_per_strip = p.tiles_x * p.Hs;
+    // Sample units (rt_kernel.hip.h): pixel slots per wave, the commit threshold, the division by spp
+    {
+        p.grp = p.spp >= 8u ? 1u : (8u + p.spp - 1u) / p.spp;            // a slot is at least 8 units
+        const uint64_t slot_units = (uint64_t)p.grp * p.spp;
+        p.grp_magic = p.grp > 1u ? (uint32_t)((1ull << 32) / p.grp) + 1u : 0u;
+        p.slot_stride = 1u + (uint32_t)slot_units;
+        // enough slots for the pixels in flight (64 lanes' units, each pixel open as long as its longest path) plus the complete
+        // ones a commit waits for; fewer at large sample counts, where a slot is kilobytes of scratch
+        const int forced = dbg(DBG_SLOTS);
+        p.n_slots = forced > 0 ? std::min<uint32_t>((uint32_t)forced, rtk::SLOTS_MAX)
+                               : (uint32_t)std::min<uint64_t>(rtk::SLOTS_MAX, std::max<uint64_t>(4u, 384u / slot_units));
+        const uint32_t cs = dbg(DBG_COMMIT_SLOTS) > 0 ? (uint32_t)dbg(DBG_COMMIT_SLOTS) : std::max<uint32_t>(1u, p.n_slots * 3u / 8u);
+        p.commit_slots = std::min<uint32_t>(cs, p.n_slots);
+        // q / d == mulhi(q, floor(2^32 / d) + 1) whenever q * d < 2^32: q < 65 * spp with spp <= RT_MAX_SPP (4096)
+        p.spp_magic = p.spp > 1u ? (uint32_t)((1ull << 32) / p.spp) + 1u : 0u;
+        p.slotu_magic = (uint32_t)((1ull << 32) / slot_units) + 1u;
+    }
     const uint64_t n_tiles = (uint64_t)p.tiles_per_strip * n;
     if (n_tiles > 0x7fffffffull) return fail(RT_ERR_LIMIT, "too many tiles in one launch");
     p.n_tiles = (uint32_t)n_tiles;
@@ -533,6 +546,36 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
         }
         p.stack_ovf = sc->d_stack_ovf;
     }
+    // the launch's ring: the one this stream used last, else a free one, else the least recently used (after its last launch)
+    rt_scene::Ring* rg = nullptr;
+    {
+        const size_t ring_bytes = (size_t)blocks * waves_per_wg * p.n_slots * p.slot_stride * 12u;
+        for (auto& r : sc->rings)
+            if (r.d && r.last == stream) { rg = &r; break; }
+        if (!rg)
+            for (auto& r : sc->rings)
+                if (!r.d) { rg = &r; break; }
+        if (!rg) {
+            rg = &sc->rings[0];
+            for (auto& r : sc->rings)
+                if (r.stamp < rg->stamp) rg = &r;
+        }
+        if (rg->bytes < ring_bytes) {
+            if (rg->d) {
+                if (rg->done) HIPCHK(hipEventSynchronize(rg->done));     // a launch in flight may still use the old area
+                (void)hipFree(rg->d);
+                rg->d = nullptr;
+                rg->bytes = 0;
+            }
+            HIPCHK(hipMalloc(&rg->d, ring_bytes));
+            rg->bytes = ring_bytes;
+        }
+        if (!rg->done) HIPCHK(hipEventCreateWithFlags(&rg->done, hipEventDisableTiming));
+        else if (rg->last != stream) HIPCHK(hipStreamWaitEvent(stream, rg->done, 0));
+        rg->last = stream;
+        rg->stamp = ++sc->ring_clock;
+        p.ring = rg->d;
+    }
     dim3 grid(blocks), block(bs);
     EvPair ev;
     int rc = get_events(sc, ev);
@@ -548,6 +591,7 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     hipLaunchKernelGGL(kern, grid, block, lds, stream, p);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ev.b, stream));
+    HIPCHK(hipEventRecord(rg->done, stream));
     if (p.stack_ovf) HIPCHK(hipEventRecord(sc->ovf_done, stream));
     sc->pending.push_back({ev.a, ev.b});
     sc->primary_rays += (uint64_t)p.Hs * p.W * p.spp * n;
@@ -1187,6 +1231,10 @@ static int rt_scene_destroy_impl(rt_scene* sc) {
     (void)hipFree(sc->d_travq);
     (void)hipFree(sc->d_stack_ovf);
     if (sc->ovf_done) (void)hipEventDestroy(sc->ovf_done);
+    for (auto& r : sc->rings) {
+        (void)hipFree(r.d);
+        if (r.done) (void)hipEventDestroy(r.done);
+    }
     (void)hipFree(sc->d_geom_r);
     (void)hipFree(sc->d_big);
     (void)hipFree(sc->d_leaf_of);

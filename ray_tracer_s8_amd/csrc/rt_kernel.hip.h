@@ -1,9 +1,10 @@
 // rt_kernel.hip.h — gfx950 path-trace tile kernel (device code).
 //
-// One work-item per pixel: a lane owns one pixel at a time and runs the reference slave's
-// whole per-pixel loop for it — thin-lens ray generation (camera.rs:109-129), closest hit
-// over the primitive list (shapes/mod.rs:158-191), shade + bounce (main.rs:108-146),
-// sample mean, gamma and RGB8 quantise (main.rs:73-81, color.rs:13-19).
+// One work-item per pixel SAMPLE: a lane owns one sample of a pixel at a time and runs the reference slave's
+// per-sample loop body for it — thin-lens ray generation (camera.rs:109-129), closest hit
+// over the primitive list (shapes/mod.rs:158-191), shade + bounce (main.rs:108-146) — and the wave then
+// sums a pixel's sample colours in the reference's order and takes the mean, gamma and RGB8 quantise
+// (main.rs:73-81, color.rs:13-19).
 //
 // Arithmetic contract: every value that reaches the image is computed with the SAME
 // IEEE-754 binary32 operations in the SAME order as the reference (oracle/rt_oracle.cpp):
@@ -12,11 +13,12 @@
 // conservative broad phase, whose value never reaches the image.
 //
 // Structure (DESIGN.md "Kernel"):
-//   * persistent waves: the grid is sized to the chip, every wave pulls 8x8-pixel tiles of
-//     the requested strips from a global atomic queue; inside a wave, a lane whose pixel
-//     is finished pulls the next pixel of the wave's current tile, and a lane whose path
-//     ends starts the pixel's next sample at once — the sphere scan runs with a nearly
-//     full EXEC mask although path lengths vary from 1 to depth+1 segments;
+//   * persistent waves: the grid is sized to the chip, every wave pulls tiles of 64x1 pixels of
+//     the requested strips from a global atomic queue; a tile is 64 * spp SAMPLE UNITS in pixel-major
+//     order, a lane whose path ends deposits the sample's colour in the wave's ring and takes the wave's
+//     next unit at once — the scan / walk runs with a nearly full EXEC mask although path lengths vary
+//     from 1 to depth+1 segments, and no lane ever works through a pixel's samples one after the other;
+//     the wave commits finished units IN ORDER: a pixel's colours are summed s = 0 .. spp-1 as main.rs:73-77 does;
 //   * broad phase: wave-uniform LDS broadcast reads (ds_read_b128) of sphere pairs,
 //     packed-FP32 (v_pk_fma_f32) conservative "line misses inflated sphere" test;
 //     survivors go to a per-lane candidate list in LDS, in index order;
@@ -107,10 +109,26 @@ constexpr uint32_t LEAF_BIT = 0x80000000u;
 // Output staging (north_star: "coalesced HBM stores of the tile"): a wave collects the RGB8 bytes of up to STAGE_SLOTS of
 // its 64x1 tiles in LDS and writes a finished tile as 48 whole dwords = three whole 64-byte lines.  Byte stores of
 // single pixels reached HBM as partial lines: 1.3x (c3) to 13x (c5) write amplification (profiles/r01_*, r02_*).
-constexpr uint32_t STAGE_SLOTS = 3, STAGE_SLOTS_MAX = 5, STAGE_TILE_BYTES = 192, STAGE_BYTES = STAGE_SLOTS * STAGE_TILE_BYTES;   // (the host may grant up to STAGE_SLOTS_MAX: KParams::stage_slots)
-constexpr uint32_t STAGE_DIRECT = 7;      // slot number of a pixel that is stored directly (no free slot, ragged tile)
-// (three slots spelt out below: as arrays the slot state left the scalar registers — 9 more VGPRs, one wave per SIMD
-// less for the quantised-node kernel)
+constexpr uint32_t STAGE_TILE_BYTES = 192;
+
+// ---- Sample units (round 4).  The unit of work a lane takes is ONE SAMPLE of a pixel.  A wave keeps up to
+// n_slots PIXEL SLOTS; a slot holds a group of `grp` neighbouring pixels of a tile (one pixel from 8 samples per pixel up) = grp x spp
+// units in pixel-major order, and owns a header plus one 12-byte record per unit in the wave's scratch (global memory, L2-resident:
+// a slot is reused as soon as it is free).  Lanes take the units of the open slot, then of the next free one; a finished unit's
+// colour goes to its record and counts the slot's LDS counter down.  A slot whose counter has reached zero is COMMITTED — out of
+// order with respect to other slots, which is what keeps a long path from holding back anything but its own pixel: each of its
+// pixels is summed s = 0 .. spp-1 (the f32 sum order of main.rs:73-77), then mean, gamma, quantise — and freed.
+constexpr uint32_t SLOTS_MAX = 32;                // pixel slots per wave
+constexpr uint32_t SLOT_FREE = 0x80000000u;       // counter value of a free slot
+constexpr uint32_t STAGE_TILES = 3;               // output staging: tiles a wave may have open
+struct WaveQ {
+    uint32_t cnt[SLOTS_MAX];                     // per slot: units not yet finished (0: complete, waiting for its commit; SLOT_FREE: free)
+    uint8_t stack[SLOTS_MAX];                    // the free slots, last freed on top (a slot that was just written is reused first: L2)
+};
+struct WaveStage {                               // kernels with output staging only
+    int left[STAGE_TILES + 1];                   // pixels of the staged tile not yet committed (< 0: stage slot free)
+    uint32_t dst_lo[STAGE_TILES + 1], dst_hi[STAGE_TILES + 1];   // the tile's first byte in the strip
+};
 
 struct StripDesc {
     uint64_t seed;
@@ -134,11 +152,17 @@ struct KParams {
     uint32_t lds_rr_off;
     uint32_t lds_stack_off;      // traversal engine: per-lane stack, (bvh depth + 1) x 256 x u32
     uint32_t lds_cmp_off;        // compacted root tests (ISECT 2): 1 KiB per wave (offsets, distances, roots, hit flags); 0xffffffff: per-lane flush
-    uint32_t stage_slots;        // output staging: tiles a wave can hold in LDS (STAGE_SLOTS..STAGE_SLOTS_MAX)
-    uint32_t lds_stage_off;      // output staging (STAGE_BYTES per wave); 0xffffffff: every pixel is stored directly
+    uint32_t lds_stage_off;      // output staging (STAGE_TILE_BYTES per wave); 0xffffffff: every pixel is stored directly
     uint32_t n_strips;           // strips in this launch
-    uint32_t tiles_x, tiles_per_strip, n_tiles;   // tiles of 64 pixels: (1 << tile_wlog2) wide
-    uint32_t tile_wlog2;         // 3: 8x8 tiles, 6: 64x1 tiles (three whole 64-B lines of RGB8 per tile row)
+    uint32_t tiles_x, tiles_per_strip, n_tiles;   // tiles of 64x1 pixels (three whole 64-B lines of RGB8 per tile)
+    uint32_t n_slots;            // sample units: pixel slots per wave (<= SLOTS_MAX)
+    uint32_t grp;                //   pixels per slot (1 from 8 spp up; 8 / spp below, so that a slot is at least 8 units)
+    uint32_t grp_magic;          //   floor(2^32 / grp) + 1 (grp > 1)
+    uint32_t slot_stride;        //   12-byte records per slot in the scratch: header + grp x spp
+    uint32_t commit_slots;       //   a commit is worth its instructions once this many slots are complete
+    uint32_t spp_magic;          //   floor(2^32 / spp) + 1: q / spp == mulhi(q, magic) for q < 65 * spp (spp <= RT_MAX_SPP = 4096); 0 for spp 1
+    uint32_t slotu_magic;        //   floor(2^32 / U) + 1, U = grp * spp the units of a full slot: q / U == mulhi(q, magic) for q < 65 * U
+    float* ring;                 //   [waves of the grid][n_slots][slot_stride][3]: slot header (x, row, meta), then (r, g, b) per unit
     float org[3], llc[3], hor[3], ver[3];   // Camera::new (camera.rs:19-47), host-computed
     float lens_radius, focus_distance;
     float u_den, v_den;          // aspect*H_f - 1, H_f - 1 (camera.rs:115-117)
@@ -277,8 +301,9 @@ __device__ __forceinline__ uint64_t splitmix_mix(uint64_t z) {
     return z ^ (z >> 31);
 }
 constexpr uint64_t PHI = 0x9e3779b97f4a7c15ull;
-__device__ __forceinline__ Rng seed_pixel(uint64_t job_seed, uint64_t pixel_index) {
-    uint64_t st = splitmix_mix(job_seed + (pixel_index + 1) * PHI);   // DESIGN.md "RNG"
+// DESIGN.md "RNG": sample s of pixel p (global index) of a job with S samples per pixel draws from
+// SmallRng::seed_from_u64(job_seed + 4 * PHI * (p * S + s)) — block p * S + s of four consecutive SplitMix64 outputs of the job seed
+__device__ __forceinline__ Rng seed_state(uint64_t st) {               // st = job_seed + 4 * PHI * (p * S + s)
     Rng r;                                                              // seed_from_u64
     st += PHI; r.s0 = splitmix_mix(st);
     st += PHI; r.s1 = splitmix_mix(st);
@@ -547,6 +572,9 @@ __device__ __forceinline__ const T& at32(const T* __restrict__ base, uint32_t i)
     return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + i * (uint32_t)sizeof(T));
 }
 
+// a wave-uniform value read through a vector register (LDS): back into a scalar register
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
 // Slab values of the two child boxes of a QNode (rt_bvh.h: centre c and half-extent h per axis, 16-bit grid units) for a ray
 // carried in grid units, t(q) = q * ig + cq: per axis and child tc = fma(c, ig, cq) is the slab centre and
 // near / far = tc -+ h |ig| — whichever the sign of the direction — so the slab test needs no min / max per plane: three
@@ -605,6 +633,19 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
     // the workgroup's share of the tile queue: [next | end << 32], a refill lock, and "the launch's queue is empty"
     __shared__ unsigned long long wg_tiles;
     __shared__ unsigned int wg_lock, wg_drained;
+    __shared__ WaveQ wave_q[BS / 64];                    // sample units: per-wave bookkeeping (see WaveQ)
+    constexpr bool CAN_STAGE = (ISECT >= 1 && ISECT <= 4) || ISECT >= 7;     // output staging compiled in (see there)
+    __shared__ WaveStage wave_st[CAN_STAGE ? BS / 64 : 1];
+    {
+        uint32_t* z = reinterpret_cast<uint32_t*>(&wave_q[threadIdx.x >> 6]);
+        // every slot free: counters SLOT_FREE, the stack holds n_slots - 1 ... 0 (slot 0 on top)
+        if ((threadIdx.x & 63u) < SLOTS_MAX) {
+            wave_q[threadIdx.x >> 6].cnt[threadIdx.x & 63u] = SLOT_FREE;
+            wave_q[threadIdx.x >> 6].stack[threadIdx.x & 63u] = (uint8_t)(p.n_slots - 1u - min(threadIdx.x & 63u, p.n_slots - 1u));
+        }
+        (void)z;
+        if (CAN_STAGE && (threadIdx.x & 63u) <= STAGE_TILES) wave_st[threadIdx.x >> 6].left[threadIdx.x & 63u] = -1;
+    }
     if (threadIdx.x == 0) {
         wg_tiles = 0ull;
         wg_lock = 0u;
@@ -678,16 +719,25 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
     const float KMf = 1.0f - 0x1p-17f;              // broad-phase margin
     const v2f NKM = {-KMf, -KMf};
 
-    // ---- wave-uniform tile cursor (kept identical in every live lane)
-    uint32_t tile_pos = 64;
-    uint32_t tile_strip = 0, tile_x0 = 0, tile_y0 = 0, tile_yg0 = 0;   // decoded once per tile
-    uint64_t tile_seed = 0;
-    // ---- per-lane pixel state
-    bool have_pixel = false, retired = false, need_ray = false;
-    uint32_t px = 0, pyg = 0, strip = 0;      // pixel column, GLOBAL row (main.rs:66-68), strip index in the batch
+    // ---- sample units: wave-uniform cursors (identical in every lane; all 64 lanes stay in the loop until the wave is done)
+    const uint32_t wave = (uint32_t)tid >> 6;
+    // (wave_q is always addressed as the __shared__ array it is: through a volatile reference the accesses became flat loads
+    // with a 64-bit address register pair each; the lanes' writes and reads are ordered by wavefront-scope fences instead)
+#define wq wave_q[wave]
+#define wst wave_st[CAN_STAGE ? wave : 0u]
+    float* const ring = p.ring + (size_t)(blockIdx.x * (uint32_t)(BLOCK / 64) + wave) * ((size_t)p.n_slots * p.slot_stride * 3u);
+    uint32_t sp = p.n_slots;                  // free slots (height of wq.stack)
+    uint32_t cur_slot = 0;                    // the open slot: the one the tile's next unit belongs to (unless that unit starts a slot)
+    uint32_t tile_u = 0, tile_units = 0;      // issue tile: its next unit, its units (npix * spp); pixel-major: unit = pixel-in-tile * spp + sample
+    uint32_t tile_x0 = 0, tile_row = 0, tile_yg = 0;   // ... decoded once: first column, row within the strip, GLOBAL row (main.rs:66-68)
+    uint32_t tile_meta = STAGE_TILES << 16;   // ... strip in the batch | stage slot << 16 (STAGE_TILES: its pixels are stored directly)
+    uint64_t tile_seed = 0;                   // ... SplitMix64 state of its first unit's stream
+    bool q_drained = false;                   // the launch's queue has no tile left for this wave
+    // ---- per-lane state
+    bool have_unit = false, need_ray = false;
+    uint32_t useq = 0;                        // the lane's unit: slot << 24 | unit within the slot
+    uint32_t px = 0, pyg = 0;                 // its pixel: column, GLOBAL row — live from acquisition to the camera ray only
     Rng rng = {0, 0, 0, 0};
-    float sum_r = 0.f, sum_g = 0.f, sum_b = 0.f;
-    uint32_t s_idx = 0;          // samples finished
     uint32_t depth_left = 0, k = 0;
     V3 o = mk(0, 0, 0), d = mk(0, 0, 0);
     bool bounce = false;         // need_ray kind: false = camera ray of a new sample, true = scattered ray
@@ -744,68 +794,180 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
         n_seg = n_cand = n_fall = 0;
         n_int = 0;
     };
-    // ---- output staging (see STAGE_SLOTS).  Slot bookkeeping is wave-uniform (scalar registers): pixels still to
-    // come per slot (< 0: free) and the tile's address in the strip; only the 192 data bytes per slot live in LDS.
-    // Compiled into the kernels whose gathers churn L2 (the L2-gather walks, the streamed scan): there a pixel's line
-    // is evicted half written.  The LDS-tree and resident-scan kernels leave L2 to the frame: their byte stores merge
-    // there into whole lines (c3: WRITE_SIZE 1.03 x the frame either way, profiles/r02_*), staging only cost registers.
-    constexpr bool CAN_STAGE = (ISECT >= 1 && ISECT <= 4) || ISECT >= 7;
+    // ---- output staging (north_star: "coalesced HBM stores of the tile"): a wave collects the RGB8 bytes of up to STAGE_TILES of
+    // its 64x1 tiles in LDS (192 bytes each) and writes a finished tile as 48 dwords = three whole 64-byte lines; a tile that finds
+    // no free stage slot is stored pixel by pixel.  Compiled into the kernels whose gathers churn L2 (the L2-gather walks, the
+    // streamed scan): there a pixel's line is evicted half written (1.3 x ... 13 x write amplification, profiles/r01_*).  The
+    // LDS-tree and resident-scan kernels leave L2 to the frame: their byte stores merge there into whole lines.
     const bool staging = CAN_STAGE && p.lds_stage_off != 0xffffffffu;
-    unsigned char* const stage_base = lds_raw + (staging ? p.lds_stage_off + (uint32_t)(tid >> 6) * (p.stage_slots * STAGE_TILE_BYTES) : 0u);
-    int s_left0 = -1, s_left1 = -1, s_left2 = -1, s_left3 = -1, s_left4 = -1;
-    uint8_t *s_dst0 = nullptr, *s_dst1 = nullptr, *s_dst2 = nullptr, *s_dst3 = nullptr, *s_dst4 = nullptr;
-    uint32_t tile_slot = STAGE_DIRECT;        // slot of the wave's current tile
-    uint32_t fin_slot = STAGE_DIRECT;         // per lane: slot of the pixel it finished in the last pass
+    unsigned char* const stage_base = lds_raw + (staging ? p.lds_stage_off + wave * (STAGE_TILES * STAGE_TILE_BYTES) : 0u);
+    // tile number -> strip in the batch, first column, row within the strip
+    auto decode_tile = [&](uint32_t t, uint32_t& st, uint32_t& x0, uint32_t& row) {
+        st = t / p.tiles_per_strip;
+        const uint32_t rem = t - st * p.tiles_per_strip;
+        row = rem / p.tiles_x;
+        x0 = (rem - row * p.tiles_x) << 6;
+    };
+    // q / spp for q < 65 * spp (a unit's place in its tile -> its pixel): a multiply-high (spp 1: the unit itself)
+    auto div_spp = [&](uint32_t q) -> uint32_t { return p.spp_magic ? __umulhi(q, p.spp_magic) : q; };
 
     TDECL;
     for (;;) {
         WCOUNT(0);
         TSTAMP(5);
-        if (staging && __ballot(fin_slot != STAGE_DIRECT)) {
-            // ================= finished tiles: LDS -> three whole lines of the strip, by whatever lanes are left
-            const unsigned long long m0 = __ballot(fin_slot == 0), m1 = __ballot(fin_slot == 1), m2 = __ballot(fin_slot == 2);
-            const unsigned long long m3 = __ballot(fin_slot == 3), m4 = __ballot(fin_slot == 4);
-            fin_slot = STAGE_DIRECT;
-            s_left0 -= (int)__builtin_popcountll(m0);
-            s_left1 -= (int)__builtin_popcountll(m1);
-            s_left2 -= (int)__builtin_popcountll(m2);
-            s_left3 -= (int)__builtin_popcountll(m3);
-            s_left4 -= (int)__builtin_popcountll(m4);
-            if (s_left0 == 0 || s_left1 == 0 || s_left2 == 0 || s_left3 == 0 || s_left4 == 0) {
-                const unsigned long long act = __ballot(true);
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
-                const uint32_t nact = (uint32_t)__builtin_popcountll(act);
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // the byte stores of this wave's other lanes
-                auto put = [&](uint32_t sl, uint8_t* dst) {
-                    const uint32_t* src = reinterpret_cast<const uint32_t*>(stage_base + sl * STAGE_TILE_BYTES);
-                    uint32_t* d32 = reinterpret_cast<uint32_t*>(dst);
-                    for (uint32_t i = rank; i < STAGE_TILE_BYTES / 4; i += nact) d32[i] = src[i];
-                };
-                if (s_left0 == 0) { put(0, s_dst0); s_left0 = -1; }
-                if (s_left1 == 0) { put(1, s_dst1); s_left1 = -1; }
-                if (s_left2 == 0) { put(2, s_dst2); s_left2 = -1; }
-                if (s_left3 == 0) { put(3, s_dst3); s_left3 = -1; }
-                if (s_left4 == 0) { put(4, s_dst4); s_left4 = -1; }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // reads done before the slot is written again
+        // (the cursors are wave-uniform by construction; said once per round so that they live in scalar registers)
+        sp = uni(sp); cur_slot = uni(cur_slot); tile_u = uni(tile_u); tile_units = uni(tile_units);
+        tile_x0 = uni(tile_x0); tile_row = uni(tile_row); tile_yg = uni(tile_yg); tile_meta = uni(tile_meta);
+        tile_seed = (uint64_t)uni((uint32_t)tile_seed) | ((uint64_t)uni((uint32_t)(tile_seed >> 32)) << 32);
+        q_drained = uni(q_drained ? 1u : 0u) != 0u;
+        // ================= commit: complete slots -> pixels (main.rs:73-81)
+#ifdef X_MARKS
+        asm volatile("; MARK commit begin");
+#endif
+        if (sp != p.n_slots) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");          // the lanes' deposits of the last round
+            const bool slot_done = (uint32_t)lane < SLOTS_MAX && wq.cnt[lane & (int)(SLOTS_MAX - 1u)] == 0u;
+            const uint32_t complete = (uint32_t)__ballot(slot_done);         // (an open slot's counter still holds its unissued units)
+            const uint32_t n_complete = (uint32_t)__builtin_popcount(complete);
+            // Worth the instructions?  A commit runs at one lane per pixel, so it waits until commit_slots are complete — unless
+            // the wave is about to run out of slots (lanes would go without units) or nothing is left to issue.
+            const bool issue_over = q_drained && tile_u == tile_units;
+            if (n_complete >= p.commit_slots || (n_complete != 0u && (sp < 2u || issue_over))) {
+                WCOUNT(14);
+                // the colours were stored by other lanes of this wave in earlier rounds: every store has reached L2 before the loads
+                // are issued, and the loads are of agent scope (they do not take a stale line of the CU's vector L1)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const uint32_t n_lanes = p.n_slots * p.grp;               // lane L <-> pixel L % grp of slot L / grp
+                for (uint32_t l0 = 0; l0 < n_lanes; l0 += 64u) {
+                    const uint32_t L = l0 + (uint32_t)lane;
+                    const uint32_t slot = p.grp == 1u ? L : __umulhi(L, p.grp_magic), g = L - slot * p.grp;      // (grp > 1: below 8 spp only)
+                    const bool mine = slot < p.n_slots && ((complete >> (slot & 31u)) & 1u) != 0u;
+                    if (__ballot(mine) == 0ull) continue;
+                    uint32_t stg = STAGE_TILES;
+                    bool fin = false;
+                    uint32_t pin = 0;
+                    if (mine) {
+                        const float* sb = ring + __umul24(slot, p.slot_stride) * 3u;
+                        const uint32_t hx = __hip_atomic_load(reinterpret_cast<const uint32_t*>(sb) + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const uint32_t hrow = __hip_atomic_load(reinterpret_cast<const uint32_t*>(sb) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const uint32_t hmeta = __hip_atomic_load(reinterpret_cast<const uint32_t*>(sb) + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const float* r = sb + 3u + g * p.spp * 3u;
+                        float sum_r = 0.f, sum_g = 0.f, sum_b = 0.f;
+                        if (g < ((hmeta >> 8) & 0xffu)) {                    // (the last slot of a ragged tile holds fewer pixels)
+                            // pix_color += (main.rs:75), s = 0 .. spp - 1; the loads of four samples in flight together
+                            uint32_t i = 0;
+#pragma clang loop unroll(disable)
+                            for (; i + 4u <= p.spp; i += 4u) {
+                                LCOUNT(12);
+                                float c[12];
+#pragma unroll
+                                for (int e = 0; e < 12; e++) c[e] = __hip_atomic_load(r + ((e / 3) * 3 + e % 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                                for (int e = 0; e < 4; e++) {
+                                    sum_r = sum_r + c[3 * e + 0];
+                                    sum_g = sum_g + c[3 * e + 1];
+                                    sum_b = sum_b + c[3 * e + 2];
+                                }
+                                r += 12;
+                            }
+#pragma clang loop unroll(disable)
+                            for (; i < p.spp; i++) {
+                                LCOUNT(12);
+                                const float cr = __hip_atomic_load(r + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                const float cg = __hip_atomic_load(r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                const float cb = __hip_atomic_load(r + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                sum_r = sum_r + cr;
+                                sum_g = sum_g + cg;
+                                sum_b = sum_b + cb;
+                                r += 3;
+                            }
+                            // ---- mean, gamma, quantise, store (main.rs:78-81)
+                            // pix_color / sample_count (main.rs:78-80).  When the sample count is a power of two the quotient IS the
+                            // product with its exact reciprocal (one rounding of the same real value either way, subnormal results
+                            // included), and a multiply is a tenth of an IEEE division's instructions: wave-uniform choice.
+                            float cr_, cg_, cb_;
+                            if (p.spp_rcp != 0.0f) {
+                                cr_ = __builtin_sqrtf(sum_r * p.spp_rcp);
+                                cg_ = __builtin_sqrtf(sum_g * p.spp_rcp);
+                                cb_ = __builtin_sqrtf(sum_b * p.spp_rcp);
+                            } else {
+                                cr_ = __builtin_sqrtf(sum_r / p.spp_f);
+                                cg_ = __builtin_sqrtf(sum_g / p.spp_f);
+                                cb_ = __builtin_sqrtf(sum_b / p.spp_f);
+                            }
+                            const uint32_t sidx = hmeta & 0xffu;
+                            stg = (hmeta >> 16) & 0xffu;
+                            const size_t oidx = ((size_t)hrow * p.W + hx + g) * 3;          // row within the strip
+                            if (!CAN_STAGE || stg == STAGE_TILES) {
+                                uint8_t* orgb = p.strips[sidx].rgb;
+                                orgb[oidx + 0] = f32_as_u8(cr_ * 255.999f);
+                                orgb[oidx + 1] = f32_as_u8(cg_ * 255.999f);
+                                orgb[oidx + 2] = f32_as_u8(cb_ * 255.999f);
+                            } else {
+                                uint8_t* sd = stage_base + stg * STAGE_TILE_BYTES + ((hx + g) & 63u) * 3u;
+                                sd[0] = f32_as_u8(cr_ * 255.999f);
+                                sd[1] = f32_as_u8(cg_ * 255.999f);
+                                sd[2] = f32_as_u8(cb_ * 255.999f);
+                                fin = true;
+                            }
+                            float* of = p.strips[sidx].f32;
+                            if (of) {
+                                of[oidx + 0] = cr_;
+                                of[oidx + 1] = cg_;
+                                of[oidx + 2] = cb_;
+                            }
+                            (void)pin;
+                        }
+                    }
+                    if (CAN_STAGE && __ballot(fin)) {
+                        // staged tiles that are complete now: LDS -> three whole lines of the strip
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // the byte stores of this wave's other lanes
+#pragma unroll
+                        for (uint32_t k = 0; k < STAGE_TILES; k++) {
+                            const unsigned long long mk = __ballot(fin && stg == k);
+                            if (mk == 0ull) continue;
+                            const int left = (int)uni((uint32_t)wst.left[k]) - (int)__builtin_popcountll(mk);
+                            if (left == 0) {
+                                if (lane < (int)(STAGE_TILE_BYTES / 4)) {
+                                    uint32_t* d32 = reinterpret_cast<uint32_t*>(((uintptr_t)uni(wst.dst_hi[k]) << 32) | uni(wst.dst_lo[k]));
+                                    d32[lane] = reinterpret_cast<const uint32_t*>(stage_base + k * STAGE_TILE_BYTES)[lane];
+                                }
+                            }
+                            if (lane == 0) wst.left[k] = left == 0 ? -1 : left;
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // reads done before a slot is written again
+                    }
+                }
+                // the committed slots are free again: on the stack, in any order
+                if (slot_done) {
+                    const uint32_t rk = __builtin_amdgcn_mbcnt_lo(complete, 0u);
+                    wq.stack[sp + rk] = (uint8_t)lane;
+                    wq.cnt[lane] = SLOT_FREE;
+                }
+                sp += n_complete;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             }
         }
+#ifdef X_MARKS
+        asm volatile("; MARK commit end");
+#endif
+        TSTAMP(6);
         if (TRAVERSE && __ballot(((n_seg | n_cand | n_fall | n_int) & 0x80000000u) != 0)) drain_counters();
-        // ================= pixel acquisition: lanes pull pixels of the wave's current tile
+        // ================= unit acquisition: lanes without a unit take the next units of the open slot, then of the next free slot
         {
-            bool need = !have_pixel && !retired;
-            for (;;) {
-                unsigned long long mask = __ballot(need);
-                if (mask == 0) break;
-                if (tile_pos >= 64) {                         // wave-uniform: fetch the next tile
+            bool need = !have_unit;
+            for (;;) {                                        // (one pass per tile: nearly always one)
+                if (__ballot(need) == 0ull) break;
+                if (tile_u == tile_units) {                       // wave-uniform: the issue tile is exhausted, fetch the next
+                    if (q_drained) break;
                     // Two-level tile queue.  The launch's queue head is shared by all eight XCDs, so every atomic on it
                     // is a memory-side operation (one per tile: 6 MB of "write" traffic per 4K frame on top of 25 MB of
                     // pixels, profiles/).  A workgroup therefore takes WGC = one tile per wave at a time from it and hands
                     // them to its waves through an LDS counter pair: tile-granular balance inside the workgroup, and the
                     // launch tail still one tile per wave long (waves taking private runs of tiles left 10-25 % between
                     // the average and the last wave, tools/ab.sh).
-                    unsigned long long live = __ballot(true);
                     uint32_t t = 0xffffffffu;
-                    if (lane == (int)__builtin_ctzll(live)) {
+                    if (lane == 0) {
                         constexpr uint32_t WGC = (uint32_t)(BLOCK / 64) < (uint32_t)RT_QUEUE_TAKE_MIN ? (uint32_t)RT_QUEUE_TAKE_MIN : (uint32_t)(BLOCK / 64);
                         for (;;) {
                             const unsigned long long old = __hip_atomic_fetch_add(&wg_tiles, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -838,8 +1000,8 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
                         }
                     }
                     t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-                    if (t == 0xffffffffu) {                   // queue drained: needy lanes retire
-                        if (need) retired = true;
+                    if (t == 0xffffffffu) {                   // queue drained: the wave ends when its units are committed
+                        q_drained = true;
                         break;
                     }
 #ifndef RT_TILES_TOP_DOWN
@@ -848,63 +1010,98 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
                     // cheapest tiles and the tail in which waves run half empty is shorter.
                     t = p.n_tiles - 1u - t;
 #endif
-                    // decode the tile once, wave-uniformly: strip, tile origin, strip row offset and seed
-                    const uint32_t st = t / p.tiles_per_strip;
-                    const uint32_t rem = t - st * p.tiles_per_strip;
-                    const uint32_t ty = rem / p.tiles_x;
-                    tile_strip = st;
-                    tile_x0 = (rem - ty * p.tiles_x) << p.tile_wlog2;
-                    tile_y0 = ty << (6 - p.tile_wlog2);
-                    tile_yg0 = p.strips[st].y0;
-                    tile_seed = p.strips[st].seed;
-                    tile_pos = 0;
-                    tile_slot = STAGE_DIRECT;
-                    if (staging && p.tile_wlog2 == 6 && tile_x0 + 64u <= p.W && tile_y0 < p.Hs) {
-                        // a whole 64x1 tile whose 192 bytes start dword-aligned: stage it if a slot is free
-                        uint8_t* dst = p.strips[st].rgb + ((size_t)tile_y0 * p.W + tile_x0) * 3;
+                    // decode the tile once, wave-uniformly: strip, tile origin, global row and seed
+                    uint32_t tstrip;
+                    decode_tile(t, tstrip, tile_x0, tile_row);
+                    tile_yg = p.strips[tstrip].y0 + tile_row;                     // main.rs:66-68
+                    // SplitMix64 state of the tile's first stream: seed + 4 PHI * (p * S), p = row * W + x0 the tile's first pixel
+                    tile_seed = p.strips[tstrip].seed + (((uint64_t)tile_yg * p.W + tile_x0) * p.spp) * (4ull * PHI);
+                    const uint32_t npix = min(64u, p.W - tile_x0);
+                    tile_units = npix * p.spp;
+                    tile_u = 0u;
+                    uint32_t tstage = STAGE_TILES;
+                    if (staging && npix == 64u) {
+                        // a whole 64x1 tile whose 192 bytes start dword-aligned: stage it if a stage slot is free
+                        uint8_t* dst = p.strips[tstrip].rgb + ((size_t)tile_row * p.W + tile_x0) * 3;
                         if ((reinterpret_cast<uintptr_t>(dst) & 3u) == 0) {
-                            if (s_left0 < 0) { tile_slot = 0; s_left0 = 64; s_dst0 = dst; }
-                            else if (s_left1 < 0) { tile_slot = 1; s_left1 = 64; s_dst1 = dst; }
-                            else if (s_left2 < 0) { tile_slot = 2; s_left2 = 64; s_dst2 = dst; }
-                            else if (p.stage_slots > 3u && s_left3 < 0) { tile_slot = 3; s_left3 = 64; s_dst3 = dst; }
-                            else if (p.stage_slots > 4u && s_left4 < 0) { tile_slot = 4; s_left4 = 64; s_dst4 = dst; }
+                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                            for (uint32_t k = 0; k < STAGE_TILES; k++)
+                                if ((int)uni((uint32_t)wst.left[k]) < 0) {
+                                    tstage = k;
+                                    break;
+                                }
+                            if (tstage < STAGE_TILES && lane == 0) {
+                                wst.left[tstage] = 64;
+                                wst.dst_lo[tstage] = (uint32_t)reinterpret_cast<uintptr_t>(dst);
+                                wst.dst_hi[tstage] = (uint32_t)(reinterpret_cast<uintptr_t>(dst) >> 32);
+                            }
+                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                         }
                     }
+                    tile_meta = tstrip | (tstage << 16);
                 }
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
-                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                const uint32_t avail = 64u - tile_pos;
-                const uint32_t want = (uint32_t)__builtin_popcountll(mask);
-                if (need && rank < avail) {
+                // ---- The tile's next units, all needy lanes at once: the lane of rank r takes unit tv = tile_u + r.  The tile's units
+                // are cut into slots of U = grp * spp (the last one may be short): unit tv belongs to the tile's slot number tv / U.
+                // Slots up to the one tile_u - 1 lies in are open already (that one is cur_slot); the others come off the free stack,
+                // and the lane that takes a slot's first unit sets the slot up (counter, header).
+                bool got = false;
+                uint32_t tv = 0;
+                bool stall = false;
+                {
+                    const unsigned long long mask = __ballot(need);
+                    const uint32_t want = (uint32_t)__builtin_popcountll(mask);
+                    const uint32_t U = p.slot_stride - 1u;
+                    const uint32_t k_open = __umulhi(tile_u + U - 1u, p.slotu_magic);    // slots of this tile opened so far = ceil(tile_u / U)
+                    const uint32_t slot_room = (k_open + sp) * U - tile_u;                // units until the free slots run out
+                    const uint32_t take = min(want, min(tile_units - tile_u, slot_room));
+                    stall = take < want && take == slot_room;                             // out of slots: wait for commits
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                    got = need && rank < take;
+                    tv = tile_u + rank;
+                    const uint32_t k = __umulhi(tv, p.slotu_magic);                       // tv / U
+                    const uint32_t unit = tv - __umul24(k, U);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    const uint32_t fresh = (uint32_t)wq.stack[(sp - 1u - (k - k_open)) & (SLOTS_MAX - 1u)];   // (meaningful where k >= k_open)
+                    const uint32_t slot = k >= k_open ? fresh : cur_slot;
+                    if (got) {
+                        useq = (slot << 24) | unit;
+                        if (unit == 0u) {
+                            const uint32_t un = min(U, tile_units - tv);                  // its units; its pixels: un / spp
+                            wq.cnt[slot] = un;
+                            uint32_t* hdr = reinterpret_cast<uint32_t*>(ring + __umul24(slot, p.slot_stride) * 3u);
+                            hdr[0] = tile_x0 + __umul24(k, p.grp);
+                            hdr[1] = tile_row;
+                            hdr[2] = (tile_meta & 0xffu) | (div_spp(un) << 8) | (tile_meta & 0xff0000u);
+                        }
+                    }
+                    // the cursors, wave-uniformly
+                    tile_u += take;
+                    const uint32_t n_new = __umulhi(tile_u + U - 1u, p.slotu_magic) - k_open;
+                    if (n_new) {
+                        sp -= n_new;
+                        cur_slot = uni((uint32_t)wq.stack[sp & (SLOTS_MAX - 1u)]);
+                    }
+                }
+                TSTAMP(7);
+                if (got) {
                     WCOUNT(1);
                     LCOUNT(0);
-                    const uint32_t pidx = tile_pos + rank;
-                    const uint32_t x = tile_x0 + (pidx & ((1u << p.tile_wlog2) - 1u)), y = tile_y0 + (pidx >> p.tile_wlog2);
-                    if (x < p.W && y < p.Hs) {
-                        px = x;
-                        strip = tile_strip | (tile_slot << 8);       // strip index in the batch, staging slot of the pixel's tile
-                        const uint32_t yg = tile_yg0 + y;                         // main.rs:66-68
-                        pyg = yg;
-#ifdef RT_PROBE_CHEAP_SEED
-                        // timing probe (wrong images): what would acquisition cost without the five SplitMix64 rounds per pixel?
-                        {
-                            const uint64_t h_ = tile_seed + ((uint64_t)yg * p.W + x + 1) * PHI;
-                            rng.s0 = h_; rng.s1 = h_ ^ 0x9e3779b9ull; rng.s2 = ~h_; rng.s3 = h_ + 12345u;
-                        }
-#else
-                        rng = seed_pixel(tile_seed, (uint64_t)yg * p.W + x);
-#endif
-                        sum_r = sum_g = sum_b = 0.f;
-                        s_idx = 0;
-                        have_pixel = true;
-                        need_ray = true;
-                        need = false;
-                    }
+                    px = tile_x0 + div_spp(tv);                                   // pixel-major: pixel tv / spp, sample tv % spp
+                    pyg = tile_yg;
+                    // stream p * S + s: the tile's first stream + tv (tile_seed holds that one's SplitMix64 state)
+                    rng = seed_state(tile_seed + (uint64_t)tv * (4ull * PHI));
+                    have_unit = true;
+                    need_ray = true;
+                    bounce = false;
+                    need = false;
                 }
-                tile_pos += min(want, avail);
+                if (stall) break;
             }
         }
-        const bool active = have_pixel;
+        const bool active = have_unit;
+#ifdef X_MARKS
+        asm volatile("; MARK acq end");
+#endif
         TSTAMP(0);
         if (active && need_ray) {
             // ---- next ray of the lane: the camera ray of a new sample (Camera::get_ray, camera.rs:109-129) or the
@@ -956,10 +1153,12 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
             bounce = false;
         }
         TSTAMP(1);
+        // the wave is done when nothing is left to issue and everything issued is committed (wave-uniform: the lanes leave together)
+        const bool wave_busy = __ballot(active) != 0ull || sp != p.n_slots || !q_drained || tile_u != tile_units;
         if (STREAMED) {
-            if (!__syncthreads_or(active ? 1 : 0)) break;
+            if (!__syncthreads_or(wave_busy ? 1 : 0)) break;
         } else {
-            if (!active) break;
+            if (!wave_busy) break;
         }
 
         // ================= closest hit (shapes/mod.rs:158-191) =================
@@ -1331,7 +1530,7 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
             };
             for (;;) {
                 const uint32_t walking = (uint32_t)__builtin_popcountll(__ballot(in_trav));
-                const uint32_t live = (uint32_t)__builtin_popcountll(__ballot(true));
+                const uint32_t live = (uint32_t)__builtin_popcountll(__ballot(active));     // (lanes without a unit idle in the loop)
                 if (walking == 0 || (walking * 8 <= live * p.refill_eighths && walking < live)) break;
                 if (in_trav && t_cnt > p.maxl - (uint32_t)STEPS) flush();          // room for a block of appends
                 // Partial rounds of root tests.  The flush after the walk runs as many rounds as the LONGEST list among the
@@ -1364,7 +1563,7 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
             } else {
             for (;;) {
                 const uint32_t walking = (uint32_t)__builtin_popcountll(__ballot(in_trav));
-                const uint32_t live = (uint32_t)__builtin_popcountll(__ballot(true));
+                const uint32_t live = (uint32_t)__builtin_popcountll(__ballot(active));
                 if (walking == 0 || (walking * 8 <= live * p.refill_eighths && walking < live)) break;
 #ifndef RT_FLUSH_INLINE
                 // a lane whose leaf list is full waits at its leaf until this point (keeps the root tests out of the
@@ -1837,54 +2036,15 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
                         term_b = ma.z * term_b;
                     }
                 }
-                sum_r = sum_r + term_r;                      // pix_color += (main.rs:75)
-                sum_g = sum_g + term_g;
-                sum_b = sum_b + term_b;
-                s_idx++;
-                need_ray = true;
-                if (s_idx == p.spp) {
-                    WCOUNT(14);
-                    LCOUNT(12);
-                    // ---- mean, gamma, quantise, store (main.rs:78-81)
-#ifdef RT_PROBE_CHEAP_FINAL
-                    // timing probe (wrong images): the pixel's mean / gamma without the three divisions and square roots
-                    float r = sum_r * 0.1f, g = sum_g * 0.1f, b = sum_b * 0.1f;
-#else
-                    // pix_color / sample_count (main.rs:78-80).  When the sample count is a power of two the quotient IS the
-                    // product with its exact reciprocal (one rounding of the same real value either way, subnormal results
-                    // included), and a multiply is a tenth of an IEEE division's instructions: wave-uniform choice.
-                    float r, g, b;
-                    if (p.spp_rcp != 0.0f) {
-                        r = __builtin_sqrtf(sum_r * p.spp_rcp);
-                        g = __builtin_sqrtf(sum_g * p.spp_rcp);
-                        b = __builtin_sqrtf(sum_b * p.spp_rcp);
-                    } else {
-                        r = __builtin_sqrtf(sum_r / p.spp_f);
-                        g = __builtin_sqrtf(sum_g / p.spp_f);
-                        b = __builtin_sqrtf(sum_b / p.spp_f);
-                    }
-#endif
-                    const uint32_t pslot = strip >> 8, sidx = strip & 0xffu;
-                    size_t oidx = ((size_t)(pyg - p.strips[sidx].y0) * p.W + px) * 3;      // row within the strip
-                    if (!CAN_STAGE || pslot == STAGE_DIRECT) {
-                        uint8_t* orgb = p.strips[sidx].rgb;
-                        orgb[oidx + 0] = f32_as_u8(r * 255.999f);
-                        orgb[oidx + 1] = f32_as_u8(g * 255.999f);
-                        orgb[oidx + 2] = f32_as_u8(b * 255.999f);
-                    } else {
-                        volatile uint8_t* sd = stage_base + pslot * STAGE_TILE_BYTES + (px & 63u) * 3u;
-                        sd[0] = f32_as_u8(r * 255.999f);
-                        sd[1] = f32_as_u8(g * 255.999f);
-                        sd[2] = f32_as_u8(b * 255.999f);
-                        fin_slot = pslot;
-                    }
-                    float* of = p.strips[sidx].f32;
-                    if (of) {
-                        of[oidx + 0] = r;
-                        of[oidx + 1] = g;
-                        of[oidx + 2] = b;
-                    }
-                    have_pixel = false;
+                // ---- the sample's colour goes to the unit's record; the wave sums a pixel's colours in order when it commits the slot
+                {
+                    const uint32_t slot = useq >> 24;
+                    float* r = ring + (__umul24(slot, p.slot_stride) + 1u + (useq & 0xffffffu)) * 3u;
+                    r[0] = term_r;
+                    r[1] = term_g;
+                    r[2] = term_b;
+                    (void)__hip_atomic_fetch_add(&wq.cnt[slot], 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    have_unit = false;
                 }
             }
         }
@@ -1893,6 +2053,8 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
 
     drain_counters();
     TFLUSH;
+#undef wq
+#undef wst
 }
 
 // The kernels are instantiated in rt_kernels_lin.hip / rt_kernels_trav.hip; the host side (rt_api.hip) gets them here.

@@ -17,8 +17,8 @@ sph, tri, rq = scenes.config_world(sys.argv[1] if len(sys.argv) > 1 else "c3")
 reqs = []
 for k in range(rq.divisions):
     r = rq.copy(); r.division_no = k; r.flags = int(sys.argv[2]) if len(sys.argv) > 2 else 0; reqs.append(r)
-names = ["pixel acquisition", "ray generation", "traversal steps (+ inline flushes)", "root tests (flush)",
-         "shade + finish + store", "loop top / counter drain", "-", "-"]
+names = ["unit acquisition: seeding", "ray generation", "traversal steps (+ inline flushes)", "root tests (flush)",
+         "shade + deposit", "loop top", "commit (ordered sums, mean / gamma / store)", "unit acquisition: slot assignment"]
 hip = _abi.hip_runtime()
 nb = (rq.height // rq.divisions) * rq.width * 3
 with rt.Scene(0, rt.World(sph, tri)) as sc:
