@@ -95,12 +95,13 @@ enum DebugKnob {
     DBG_COMMIT_SLOTS,      // RT_COMMIT_SLOTS    sample units: complete slots a commit waits for; 0: host rule             (default 0)
     DBG_VERBOSE,           // RT_VERBOSE         engine / LDS plan of every launch on stderr                 (default 0)
     DBG_REORDER,           // RT_REORDER         0: primitive records stay in the caller's order (A/B)          (default 1)
+    DBG_TAIL_TILES,        // RT_TAIL_TILES      tiles at the end of a launch's queue handed out in quarters; -1: host rule (default -1)
     DBG_N
 };
 std::atomic<int> g_dbg[DBG_N];
 const struct { const char* env; int def; } g_dbg_spec[DBG_N] = {
     {"RT_LDS_TREE", 1}, {"RT_CULL_WALK", -1}, {"RT_NO_STAGE", 0}, {"RT_SLOTS", 0}, {"RT_FORCE_CAPPED", 0},
-    {"RT_STACK_LDS", 0}, {"RT_COMPACT", 1}, {"RT_REFILL_EIGHTHS", 0}, {"RT_COMMIT_SLOTS", 0}, {"RT_VERBOSE", 0}, {"RT_REORDER", 1}};
+    {"RT_STACK_LDS", 0}, {"RT_COMPACT", 1}, {"RT_REFILL_EIGHTHS", 0}, {"RT_COMMIT_SLOTS", 0}, {"RT_VERBOSE", 0}, {"RT_REORDER", 1}, {"RT_TAIL_TILES", -1}};
 std::once_flag g_dbg_once;
 void dbg_load_env() {
     std::call_once(g_dbg_once, [] {
@@ -495,8 +496,10 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
         p.slotu_magic = (uint32_t)((1ull << 32) / slot_units) + 1u;
     }
     const uint64_t n_tiles = (uint64_t)p.tiles_per_strip * n;
-    if (n_tiles > 0x7fffffffull) return fail(RT_ERR_LIMIT, "too many tiles in one launch");
-    p.n_tiles = (uint32_t)n_tiles;
+    if (n_tiles > 0x1fffffffull) return fail(RT_ERR_LIMIT, "too many tiles in one launch");
+    p.tiles_total = (uint32_t)n_tiles;
+    p.n_tiles = (uint32_t)n_tiles;             // (queue entries: the split into whole tiles and quarters follows the grid below)
+    p.tiles_big = (uint32_t)n_tiles;
     for (uint32_t i = 0; i < n; i++) {
         p.strips[i].seed = rqs[i].seed;
         p.strips[i].rgb = (uint8_t*)d_rgb[i];
@@ -530,6 +533,13 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     const uint32_t waves_per_wg = (uint32_t)bs / 64u;
     const uint32_t useful = (p.n_tiles + waves_per_wg - 1) / waves_per_wg;   // a wave needs at least one tile
     if (blocks > useful) blocks = useful ? useful : 1;
+    // The launch's tail is one queue entry long: its last entries — two per wave of the grid — are quarter tiles (16 pixels).
+    {
+        const int forced = dbg(DBG_TAIL_TILES);
+        const uint64_t conv = std::min<uint64_t>(p.tiles_total, forced >= 0 ? (uint64_t)forced : 2ull * blocks * waves_per_wg);
+        p.tiles_big = p.tiles_total - (uint32_t)conv;
+        p.n_tiles = p.tiles_big + 4u * (uint32_t)conv;
+    }
     p.ovf_stride = blocks * (uint32_t)bs;
     p.stack_ovf = nullptr;
     if (traverse && capped) {

@@ -154,7 +154,11 @@ struct KParams {
     uint32_t lds_cmp_off;        // compacted root tests (ISECT 2): 1 KiB per wave (offsets, distances, roots, hit flags); 0xffffffff: per-lane flush
     uint32_t lds_stage_off;      // output staging (STAGE_TILE_BYTES per wave); 0xffffffff: every pixel is stored directly
     uint32_t n_strips;           // strips in this launch
-    uint32_t tiles_x, tiles_per_strip, n_tiles;   // tiles of 64x1 pixels (three whole 64-B lines of RGB8 per tile)
+    uint32_t tiles_x, tiles_per_strip;            // tiles of 64x1 pixels (three whole 64-B lines of RGB8 per tile)
+    uint32_t tiles_total;        // tiles of the launch (tiles_per_strip * n_strips)
+    uint32_t tiles_big;          // the first tiles_big entries of the launch's queue are whole tiles, every later one is a QUARTER (16 pixels)
+                                 //   of one of the remaining tiles: the launch ends on small pieces (its tail is one piece long)
+    uint32_t n_tiles;            // queue entries: tiles_big + 4 * (tiles_total - tiles_big)
     uint32_t n_slots;            // sample units: pixel slots per wave (<= SLOTS_MAX)
     uint32_t grp;                //   pixels per slot (1 from 8 spp up; 8 / spp below, so that a slot is at least 8 units)
     uint32_t grp_magic;          //   floor(2^32 / grp) + 1 (grp > 1)
@@ -816,10 +820,12 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
         WCOUNT(0);
         TSTAMP(5);
         // (the cursors are wave-uniform by construction; said once per round so that they live in scalar registers)
+#ifdef X_UNI_TOP
         sp = uni(sp); cur_slot = uni(cur_slot); tile_u = uni(tile_u); tile_units = uni(tile_units);
         tile_x0 = uni(tile_x0); tile_row = uni(tile_row); tile_yg = uni(tile_yg); tile_meta = uni(tile_meta);
         tile_seed = (uint64_t)uni((uint32_t)tile_seed) | ((uint64_t)uni((uint32_t)(tile_seed >> 32)) << 32);
         q_drained = uni(q_drained ? 1u : 0u) != 0u;
+#endif
         // ================= commit: complete slots -> pixels (main.rs:73-81)
 #ifdef X_MARKS
         asm volatile("; MARK commit begin");
@@ -848,12 +854,14 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
                     uint32_t pin = 0;
                     if (mine) {
                         const float* sb = ring + __umul24(slot, p.slot_stride) * 3u;
+                        // (header and the first samples are asked for together: one trip to L2, not two; a lane beyond the slot's
+                        // pixels — the short last slot of a tile — sums records nobody wrote and stores nothing)
                         const uint32_t hx = __hip_atomic_load(reinterpret_cast<const uint32_t*>(sb) + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         const uint32_t hrow = __hip_atomic_load(reinterpret_cast<const uint32_t*>(sb) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         const uint32_t hmeta = __hip_atomic_load(reinterpret_cast<const uint32_t*>(sb) + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         const float* r = sb + 3u + g * p.spp * 3u;
                         float sum_r = 0.f, sum_g = 0.f, sum_b = 0.f;
-                        if (g < ((hmeta >> 8) & 0xffu)) {                    // (the last slot of a ragged tile holds fewer pixels)
+                        {
                             // pix_color += (main.rs:75), s = 0 .. spp - 1; the loads of four samples in flight together
                             uint32_t i = 0;
 #pragma clang loop unroll(disable)
@@ -861,7 +869,7 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
                                 LCOUNT(12);
                                 float c[12];
 #pragma unroll
-                                for (int e = 0; e < 12; e++) c[e] = __hip_atomic_load(r + ((e / 3) * 3 + e % 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                for (int e = 0; e < 12; e++) c[e] = __hip_atomic_load(r + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
                                 for (int e = 0; e < 4; e++) {
                                     sum_r = sum_r + c[3 * e + 0];
@@ -881,6 +889,8 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
                                 sum_b = sum_b + cb;
                                 r += 3;
                             }
+                        }
+                        if (g < ((hmeta >> 8) & 0xffu)) {                    // (the last slot of a ragged tile holds fewer pixels)
                             // ---- mean, gamma, quantise, store (main.rs:78-81)
                             // pix_color / sample_count (main.rs:78-80).  When the sample count is a power of two the quotient IS the
                             // product with its exact reciprocal (one rounding of the same real value either way, subnormal results
@@ -944,7 +954,7 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
                     wq.stack[sp + rk] = (uint8_t)lane;
                     wq.cnt[lane] = SLOT_FREE;
                 }
-                sp += n_complete;
+                sp = uni(sp + n_complete);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             }
         }
@@ -1004,20 +1014,32 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
                         q_drained = true;
                         break;
                     }
+                    // queue entry -> tile (and quarter of it): whole tiles first, the last ones in quarters
+                    uint32_t sub = 0u, tw = 64u;
+                    if (t >= p.tiles_big) {
+                        const uint32_t e = t - p.tiles_big;
+                        t = p.tiles_big + (e >> 2);
+                        sub = (e & 3u) << 4;
+                        tw = 16u;
+                    }
 #ifndef RT_TILES_TOP_DOWN
                     // Tiles are handed out from the END of the batch backwards: strips are listed top to bottom and the
                     // rows near the top of a frame are mostly sky (one segment per sample), so the launch ends on its
                     // cheapest tiles and the tail in which waves run half empty is shorter.
-                    t = p.n_tiles - 1u - t;
+                    t = p.tiles_total - 1u - t;
 #endif
                     // decode the tile once, wave-uniformly: strip, tile origin, global row and seed
                     uint32_t tstrip;
                     decode_tile(t, tstrip, tile_x0, tile_row);
-                    tile_yg = p.strips[tstrip].y0 + tile_row;                     // main.rs:66-68
+                    tile_x0 = uni(tile_x0 + sub);
+                    tile_row = uni(tile_row);
+                    if (tile_x0 >= p.W) continue;                 // (a quarter beyond the right edge of a ragged tile: nothing in it)
+                    tile_yg = uni(p.strips[tstrip].y0 + tile_row);                // main.rs:66-68
                     // SplitMix64 state of the tile's first stream: seed + 4 PHI * (p * S), p = row * W + x0 the tile's first pixel
                     tile_seed = p.strips[tstrip].seed + (((uint64_t)tile_yg * p.W + tile_x0) * p.spp) * (4ull * PHI);
-                    const uint32_t npix = min(64u, p.W - tile_x0);
-                    tile_units = npix * p.spp;
+                    tile_seed = (uint64_t)uni((uint32_t)tile_seed) | ((uint64_t)uni((uint32_t)(tile_seed >> 32)) << 32);
+                    const uint32_t npix = min(tw, p.W - tile_x0);
+                    tile_units = uni(npix * p.spp);
                     tile_u = 0u;
                     uint32_t tstage = STAGE_TILES;
                     if (staging && npix == 64u) {
@@ -1038,7 +1060,7 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
                             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                         }
                     }
-                    tile_meta = tstrip | (tstage << 16);
+                    tile_meta = uni(tstrip | (tstage << 16));
                 }
                 // ---- The tile's next units, all needy lanes at once: the lane of rank r takes unit tv = tile_u + r.  The tile's units
                 // are cut into slots of U = grp * spp (the last one may be short): unit tv belongs to the tile's slot number tv / U.
@@ -1075,10 +1097,10 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
                         }
                     }
                     // the cursors, wave-uniformly
-                    tile_u += take;
+                    tile_u = uni(tile_u + take);
                     const uint32_t n_new = __umulhi(tile_u + U - 1u, p.slotu_magic) - k_open;
                     if (n_new) {
-                        sp -= n_new;
+                        sp = uni(sp - n_new);
                         cur_slot = uni((uint32_t)wq.stack[sp & (SLOTS_MAX - 1u)]);
                     }
                 }
