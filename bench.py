@@ -77,6 +77,7 @@ def parse_args():
     ap.add_argument("--frame", action="store_true", help="print ONLY the frame_path object: wall-clock frames of --workload "
                     "through a persistent rt_frame_ctx (host buffer out), --steps frames after the first")
     ap.add_argument("--frame-queue", action="store_true", help="with --frame: the strip-queue assignment (RT_FLAG_FRAME_QUEUE)")
+    ap.add_argument("--frame-static", action="store_true", help="with --frame: strip k -> entry k mod n (RT_FLAG_FRAME_STATIC)")
     ap.add_argument("--frame-devices", default="", help="with --frame: comma-separated device ordinals of the frame context "
                     "(default: the rank's device); a device may be listed more than once")
     ap.add_argument("--cpu-scale", type=int, default=1, help="CPU baseline renders the frame at 1/scale resolution")
@@ -127,7 +128,11 @@ def cpu_baseline(workload: str, scale: int):
     }
 
 
-def frame_path(rt, _abi, scenes, workload: str, dev_index, frames: int = 3, queue: bool = False):
+ASSIGNMENTS = {0: "static: strip k -> entry k mod n", 1: "snake (no costs measured yet)",
+               2: "longest-first by the previous frame's per-strip ray segments", 3: "strip queue"}
+
+
+def frame_path(rt, _abi, scenes, workload: str, dev_index, frames: int = 3, queue: bool = False, static: bool = False):
     """Wall clock of the in-process product path that replaces the controller's dispatch + assembly (controller
     main.rs:47-75, 109-115): rt_frame_ctx_render into a host frame buffer — kernels, strip downloads, dispatcher
     wake-ups, everything — frame after frame of one job.  Frame 1 carries the one-off costs (page-locking the buffer,
@@ -136,6 +141,8 @@ def frame_path(rt, _abi, scenes, workload: str, dev_index, frames: int = 3, queu
     sph, tri, rq = scenes.config_world(workload)
     if queue:
         rq.flags |= _abi.RT_FLAG_FRAME_QUEUE
+    if static:
+        rq.flags |= _abi.RT_FLAG_FRAME_STATIC
     buf = np.zeros(rq.width * rq.height * 3, np.uint8)            # (zeros: the pages exist before the first frame)
     devices = list(dev_index) if isinstance(dev_index, (list, tuple)) else [dev_index]
     t0 = time.perf_counter()
@@ -151,11 +158,13 @@ def frame_path(rt, _abi, scenes, workload: str, dev_index, frames: int = 3, queu
         recs.append({"wall_ms_python": (tb - ta) * 1e3, "wall_ms": fs.wall_ms, "pin_ms": fs.pin_ms, "scene_ms": fs.scene_ms,
                      "kernel_ms": fs.kernel_ms, "d2h_exposed_ms": fs.d2h_exposed_ms, "host_ms": fs.host_ms,
                      "pinned": int(fs.pinned), "launches": int(fs.totals.n_launches),
-                     "segments": int(fs.totals.ray_segments)})
+                     "segments": int(fs.totals.ray_segments), "assignment": ASSIGNMENTS.get(int(fs.assignment), "?"),
+                     "balance": {"max_over_mean_segments": float(fs.balance_max_over_mean),
+                                 "per_entry_segments": [int(v) for v in list(fs.entry_segments)[:min(len(devices), 16)]]}})
     fc.close()
     steady = sorted(recs[1:], key=lambda r: r["wall_ms_python"])[len(recs[1:]) // 2]      # median later frame
     out = {"workload": workload, "n_devices": len(devices), "devices": devices,
-           "assignment": "strip queue" if queue else "static: strip k -> device k mod n",
+           "assignment": steady["assignment"],
            "ctx_create_ms": (t1 - t0) * 1e3, "set_world_ms": (t2 - t1) * 1e3,
            "first_frame": recs[0], "steady_frame": steady, "frames_after_first": len(recs) - 1,
            "mrays_per_s": steady["segments"] / (steady["wall_ms_python"] / 1e3) / 1e6,
@@ -237,7 +246,7 @@ def main():
         if world != 1:
             raise SystemExit("--frame is the in-process path: run it with --gpus 1")
         devs = [int(x) for x in args.frame_devices.split(",") if x != ""] or dev_index
-        print(json.dumps({"frame_path": frame_path(rt, _abi, scenes, args.workload, devs, args.steps, args.frame_queue)}), flush=True)
+        print(json.dumps({"frame_path": frame_path(rt, _abi, scenes, args.workload, devs, args.steps, args.frame_queue, args.frame_static)}), flush=True)
         return
     sph, tri, rq0 = scenes.config_world(args.workload)
     rq0.flags = args.flags
@@ -385,6 +394,19 @@ def main():
                 fpath[w] = frame_path(rt, _abi, scenes, w, dev_index, 3)
             except Exception as e:
                 fpath[w] = {"error": repr(e)}
+        # The strip assignment's balance at EIGHT entries, on the one device this run has (eight dispatcher entries on it): how
+        # evenly the ray segments fall is a property of the assignment, not of the hardware.  BASELINE c4 (32 strips) and c5 (16).
+        bal = {}
+        for w in ("c4", "c5"):
+            try:
+                st_ = frame_path(rt, _abi, scenes, w, [dev_index] * 8, 2, static=True)
+                dy_ = frame_path(rt, _abi, scenes, w, [dev_index] * 8, 2)
+                bal[w] = {"static_k_mod_n": st_["steady_frame"]["balance"], "first_frame_snake": dy_["first_frame"]["balance"],
+                          "later_frames_by_cost": dy_["steady_frame"]["balance"],
+                          "assignments": [st_["steady_frame"]["assignment"], dy_["first_frame"]["assignment"], dy_["steady_frame"]["assignment"]]}
+            except Exception as e:
+                bal[w] = {"error": repr(e)}
+        fpath["balance_8_entries_on_one_device"] = bal
     # ---- N > 1: BASELINE config 4 as the controller splits it — ONE c4 frame, strip d -> rank d mod N, max-rank time —
     # beside the weak-scaling value of the line, so that a scaling run records it at every N
     strong_c4 = None

@@ -35,10 +35,14 @@ extern "C" {
 #define RT_API __attribute__((visibility("default")))
 #endif
 
-#define RT_ABI_VERSION 3u      /* 2: rt_tile_stats.node_steps appended
+#define RT_ABI_VERSION 4u      /* 2: rt_tile_stats.node_steps appended
                                   3: `world_index` (the position of every primitive in RenderInfo.world) on the entry
                                      points that take a world; the persistent frame context rt_frame_ctx_*;
-                                     RT_FLAG_FRAME_QUEUE / RT_FLAG_FRAME_NO_PIN replace two environment variables */
+                                     RT_FLAG_FRAME_QUEUE / RT_FLAG_FRAME_NO_PIN replace two environment variables
+                                  4: the deterministic RNG is one stream per (pixel, SAMPLE) (see `seed` below: same seed,
+                                     other images than ABI 3); RT_MAX_SPP; rt_hip_runtime_path(); the frame context assigns
+                                     strips by measured cost and reports the balance (rt_frame_stats.balance_*,
+                                     RT_FLAG_FRAME_STATIC) */
 
 /* ---- status codes --------------------------------------------------------------- */
 typedef enum rt_status {
@@ -126,7 +130,10 @@ enum {
      * host-atomic queue, two launches in flight per device, instead of the static split strip k -> devices[k % n].
      * FRAME_NO_PIN: do not page-lock the caller's frame buffer (downloads then go through the runtime's staging). */
     RT_FLAG_FRAME_QUEUE = 1u << 12,
-    RT_FLAG_FRAME_NO_PIN = 1u << 13
+    RT_FLAG_FRAME_NO_PIN = 1u << 13,
+    /* FRAME_STATIC: the plain split strip k -> devices[k % n] (rounds 1-3; A/B runs, tests) instead of the default, which
+     * balances the devices by the strips' cost: see "Strip assignment" at rt_frame_ctx below. */
+    RT_FLAG_FRAME_STATIC = 1u << 14
 };
 
 typedef struct rt_tile_request {
@@ -145,8 +152,13 @@ typedef struct rt_tile_request {
     float focal_length;         /* 1.0            (main.rs:48)                                */
     float t_min;                /* 0.001          (shapes/mod.rs:12)                          */
     float t_max;                /* 1000.0         (shapes/mod.rs:13), half-open [t_min,t_max) */
-    /* new: replaces `SmallRng::from_entropy()` per row (main.rs:69) by a deterministic
-     * per-pixel xoshiro256++ stream; see DESIGN.md "RNG". */
+    /* new: replaces `SmallRng::from_entropy()` per row (main.rs:69).  Sample s (0 .. spp-1) of the pixel in global row y,
+     * column x of the frame draws from its own xoshiro256++ stream,
+     *     SmallRng::seed_from_u64(seed + 4 * 0x9E3779B97F4A7C15 * ((y * width + x) * spp + s))      (wrapping u64)
+     * i.e. the SplitMix64 sequence of `seed` cut into consecutive blocks of four outputs, one block per (pixel, sample);
+     * the pixel is the f32 sum of its samples' colours in the order s = 0, 1, ... as main.rs:73-77 forms it.  Strips of a
+     * frame rendered with one seed therefore stitch to exactly the single-strip frame.  DESIGN.md 3 "RNG";
+     * tests/test_rng_distribution.py checks the images' distribution against the reference's stream-per-row structure. */
     uint64_t seed;
     uint32_t flags;             /* RT_FLAG_*                                                  */
     uint32_t reserved;          /* must be 0                                                  */
@@ -181,6 +193,11 @@ RT_API int rt_init(int* n_devices);
 /* Refused (no effect; rt_last_error() says so) while any rt_scene is alive: destroy the scenes first. */
 RT_API void rt_shutdown(void);
 RT_API uint32_t rt_abi_version(void);
+/* The libamdhip64 file this library's HIP calls are bound to (a process may map two HIP runtimes, e.g. a PyTorch wheel's
+ * own next to ROCm's; the dynamic loader binds the library to whichever was loaded first).  A host that passes its own
+ * hipStream_t / device pointers to the *_device entry points must make them with THIS runtime.  Copies at most cap - 1
+ * characters and a terminator into buf (which may be NULL); returns the path's length, 0 if unknown. */
+RT_API size_t rt_hip_runtime_path(char* buf, size_t cap);
 RT_API const char* rt_strerror(int status);
 /* Last error message of the calling thread ("" if none). */
 RT_API const char* rt_last_error(void);
@@ -246,7 +263,7 @@ RT_API int rt_scene_render_tile_device(rt_scene* scene, const rt_tile_request* r
                                        void* d_out_f32, void* hip_stream);
 
 /* Batched form: n strips of ONE frame (all fields equal except division_no and seed) are
- * rendered by a single launch of persistent waves that pull 8x8-pixel tiles of all n strips
+ * rendered by a single launch of persistent waves that pull 64x1-pixel tiles of all n strips
  * from one queue — no per-strip launch tail.  d_out_rgb[i] receives strip i; d_out_f32 may
  * be NULL (or an array with NULL entries).  RT_ERR_BAD_ARG if the requests differ in any
  * frame-level field. */
@@ -273,13 +290,20 @@ RT_API int rt_scene_collect(rt_scene* scene, rt_tile_stats* stats);
  * registers, allocates, uploads and spawns nothing.  rt_render_frame is the one-shot wrapper (create, set world, render
  * one frame, destroy).
  *
- * Strip assignment: strip k goes to devices[k % n_devices], all strips of a device in one launch (above 64 MiB of
- * pixels per device: two, the last quarter of the strips running under the downloads of the rest) (default); with RT_FLAG_FRAME_QUEUE in req->flags the devices pull strips
- * one at a time, bottom of the frame first, two launches in flight per device.  The RGB8 strips are stitched by
- * division_no into out_rgb (H*W*3).  Same bytes either way.  No collective, no peer traffic: strips are independent.
+ * Strip assignment.  Strips are not equally expensive (sky rows: one segment per sample; ground rows bounce), and a frame
+ * is done when its slowest device is.  Default: the first frame of a job goes out in SNAKE order — strip k to entry k % n
+ * in even rows of n strips, to n-1 - k % n in odd ones: every entry gets one strip of each row, which evens out any cost
+ * profile that is close to linear in the strip's position — and the kernels count the ray segments of every strip; every
+ * later frame of the job (same world, same frame geometry) is assigned LONGEST-FIRST by those counts, each strip to the
+ * entry with the least load so far.  All strips of an entry go out in one launch (above 64 MiB of pixels per device: two,
+ * the last quarter of the strips running under the downloads of the rest).  RT_FLAG_FRAME_STATIC in req->flags: the plain
+ * split strip k -> devices[k % n]; RT_FLAG_FRAME_QUEUE: the devices pull strips one at a time, bottom of the frame first,
+ * two launches in flight per device.  The RGB8 strips are stitched by division_no into out_rgb (H*W*3).  Same bytes
+ * whatever the assignment.  No collective, no peer traffic: strips are independent.
  * req->division_no is ignored.  height % divisions must be 0 (the controller's from_vec(..).unwrap() panics otherwise). */
 
 typedef struct rt_frame_ctx rt_frame_ctx;
+#define RT_FRAME_STATS_ENTRIES 16u
 
 /* Where the wall time of one rt_frame_ctx_render call went (milliseconds).  Devices run concurrently: kernel_ms and
  * d2h_exposed_ms are those of the device that finished last. */
@@ -294,6 +318,10 @@ typedef struct rt_frame_stats {
     float host_ms;              /* wall_ms - pin_ms - kernel_ms - d2h_exposed_ms: dispatch, thread wake-up, joins      */
     uint32_t n_devices;
     uint32_t pinned;            /* 1: out_rgb is page-locked (strip downloads are direct DMA)                          */
+    uint32_t assignment;        /* 0: static k % n, 1: snake (no costs yet), 2: longest-first by the previous frame's
+                                   per-strip ray segments, 3: strip queue                                              */
+    float balance_max_over_mean;/* ray segments of the busiest entry / mean over the entries, THIS frame (1 = even)    */
+    uint64_t entry_segments[RT_FRAME_STATS_ENTRIES];   /* ray segments per entry (the first RT_FRAME_STATS_ENTRIES)    */
 } rt_frame_stats;
 
 /* devices == NULL (or n_devices <= 0) means all devices.  A device may be listed more than once (several dispatcher

@@ -10,7 +10,7 @@ import numpy as np
 
 from . import build as _build
 
-RT_ABI_VERSION = 3          # include/rt_tile.h RT_ABI_VERSION; load() refuses a library of another version
+RT_ABI_VERSION = 4          # include/rt_tile.h RT_ABI_VERSION; load() refuses a library of another version
 
 # ---- status codes (rt_status)
 RT_OK = 0
@@ -39,6 +39,7 @@ RT_FLAG_CULL_WALK = 1024
 RT_FLAG_NO_CULL_WALK = 2048
 RT_FLAG_FRAME_QUEUE = 4096          # frame-level (rt_render_frame / rt_frame_ctx_render): dynamic strip queue
 RT_FLAG_FRAME_NO_PIN = 8192         # frame-level: do not page-lock the caller's frame buffer
+RT_FLAG_FRAME_STATIC = 16384        # frame-level: strip k -> devices[k % n] instead of the cost-balanced assignment
 RT_MAX_BOUNCES = 62
 
 # numpy dtypes with the exact layout of rt_sphere / rt_triangle (no padding)
@@ -87,12 +88,13 @@ class FrameStats(C.Structure):
         ("totals", TileStats), ("wall_ms", C.c_float), ("pin_ms", C.c_float), ("scene_ms", C.c_float),
         ("kernel_ms", C.c_float), ("d2h_exposed_ms", C.c_float), ("host_ms", C.c_float),
         ("n_devices", C.c_uint32), ("pinned", C.c_uint32),
+        ("assignment", C.c_uint32), ("balance_max_over_mean", C.c_float), ("entry_segments", C.c_uint64 * 16),
     ]
 
 
 assert C.sizeof(TileRequest) == 64
 assert C.sizeof(TileStats) == 64
-assert C.sizeof(FrameStats) == 96
+assert C.sizeof(FrameStats) == 232
 
 
 def default_request(**kw) -> TileRequest:
@@ -129,6 +131,41 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     path = _build.LIB_PATH
     if build_if_missing:
         path = _build.build()
+    _lib = _bind(path)
+    return _lib
+
+
+_dbg_lib = None
+
+
+def load_debug() -> C.CDLL:
+    """The TEST library lib/librt_s8_dbg.so: the product sources plus the rt_debug_* hooks (build.py).  A second, independent
+    instance of the library in the process (its own rt_init state)."""
+    global _dbg_lib
+    if _dbg_lib is None:
+        _dbg_lib = _bind(_build.build_debug())
+        _dbg_lib.rt_debug_set.argtypes = [C.c_char_p, C.c_int]
+        _dbg_lib.rt_debug_set.restype = C.c_int
+    return _dbg_lib
+
+
+class debug_library:
+    """`with _abi.debug_library():` — everything the package does inside the block (rt.init(), Scene, FrameContext, debug_set)
+    goes to the test library instead of the product library.  Tests and tools only."""
+
+    def __enter__(self):
+        global _lib
+        self._prev = _lib
+        _lib = load_debug()
+        return _lib
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self._prev
+        return False
+
+
+def _bind(path: Path) -> C.CDLL:
     if not path.exists():
         raise FileNotFoundError(
             f"{path} not found: the HIP extension is required (run `python -m ray_tracer_s8_amd.build`); "
@@ -184,10 +221,6 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     lib.rt_frame_ctx_release_buffer.restype = C.c_int
     lib.rt_frame_ctx_destroy.argtypes = [vp]
     lib.rt_frame_ctx_destroy.restype = None
-    # test / tool hook, not part of rt_tile.h: one knob of the launch path by its environment-variable name
-    lib.rt_debug_set.argtypes = [C.c_char_p, C.c_int]
-    lib.rt_debug_set.restype = C.c_int
-    _lib = lib
     return lib
 
 
@@ -222,14 +255,14 @@ def as_world_index(a, n: int):
 
 
 def hip_runtime_path() -> str:
-    """The libamdhip64 file the library's HIP calls are bound to (rt_debug_hip_runtime).  PyTorch wheels bundle their own
+    """The libamdhip64 file the library's HIP calls are bound to (rt_hip_runtime_path).  PyTorch wheels bundle their own
     runtime; whichever of torch / this library is loaded FIRST decides which one this library uses
     (profiles/README.md, "two HIP runtimes in one process")."""
     lib = load()
-    lib.rt_debug_hip_runtime.argtypes = [C.c_char_p, C.c_size_t]
-    lib.rt_debug_hip_runtime.restype = C.c_size_t
+    lib.rt_hip_runtime_path.argtypes = [C.c_char_p, C.c_size_t]
+    lib.rt_hip_runtime_path.restype = C.c_size_t
     buf = C.create_string_buffer(4096)
-    return buf.value.decode() if lib.rt_debug_hip_runtime(buf, 4096) else ""
+    return buf.value.decode() if lib.rt_hip_runtime_path(buf, 4096) else ""
 
 
 def hip_runtime() -> C.CDLL:
@@ -263,7 +296,11 @@ def check_single_hip_runtime() -> None:
 def debug_set(name: str, value: int) -> int:
     """Set a launch-path knob (RT_FORCE_CAPPED, RT_STACK_LDS, RT_CULL_WALK, ...: csrc/rt_api.hip DebugKnob); returns the
     previous value.  Tests and tools only."""
-    prev = load().rt_debug_set(name.encode(), int(value))
+    lib = load()
+    if not hasattr(lib, "rt_debug_set"):
+        raise RuntimeError("debug_set needs the test library: use it inside `with _abi.debug_library():` (the product library "
+                           "exports no rt_debug_* hooks)")
+    prev = lib.rt_debug_set(name.encode(), int(value))
     if prev == -2**31:
         raise KeyError(name)
     return prev

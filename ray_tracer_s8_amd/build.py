@@ -46,11 +46,18 @@ UNITS = [
 
 
 def _deps() -> list[Path]:
-    return [CSRC / u for u, _ in UNITS] + [CSRC / "rt_kernel.hip.h", CSRC / "rt_cull.h", CSRC / "rt_bvh.h", ROOT / "include" / "rt_tile.h",
+    return [CSRC / u for u, _ in UNITS] + [CSRC / "rt_kernel.hip.h", CSRC / "rt_cull.h", CSRC / "rt_bvh.h", CSRC / "rt_assign.h", ROOT / "include" / "rt_tile.h",
                                             Path(__file__)]
 
 
 FLAGS_PATH = LIB_PATH.with_suffix(".flags")      # the exact compile lines of the library next to it
+
+# The TEST library: the product sources plus -DRT_DEBUG_HOOKS, which compiles the rt_debug_* entry points (launch-path knobs,
+# counter read-back, a throwing body, the sqrt self-test) that tests and tools use.  The product library exports exactly
+# include/rt_tile.h (tests/test_abi.py checks both).
+DEBUG_VARIANT = "dbg"
+DEBUG_FLAGS = ["-DRT_DEBUG_HOOKS"]
+DEBUG_LIB_PATH = LIB_DIR / f"librt_s8_{DEBUG_VARIANT}.so"
 
 
 def _extra_flags() -> list[str]:
@@ -83,16 +90,11 @@ def needs_build() -> bool:
     return any(d.stat().st_mtime > t for d in _deps())
 
 
-def build(force: bool = False, verbose: bool = False) -> Path:
-    """Compile librt_s8.so if missing or stale.  Raises on failure (no fallback)."""
-    if not force and not needs_build():
-        return LIB_PATH
+def _compile(lib_path: Path, flags_path: Path, obj_dir: Path, extra: list[str], verbose: bool) -> Path:
     LIB_DIR.mkdir(parents=True, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "hipcc")
-    extra = _extra_flags()
-    if FLAGS_PATH.exists():
-        FLAGS_PATH.unlink()                       # no record while the objects are in flux
-    obj_dir = LIB_DIR / (f"obj_{VARIANT}" if VARIANT else "obj")
+    if flags_path.exists():
+        flags_path.unlink()                       # no record while the objects are in flux
     obj_dir.mkdir(exist_ok=True)
     common = [f for f in HIPCC_FLAGS if f != "-shared"] + extra + [f"-I{ROOT / 'include'}", f"-I{CSRC}"]
     cmds, objs = [], []
@@ -100,7 +102,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
         obj = obj_dir / (Path(unit).stem + ".o")
         objs.append(str(obj))
         cmds.append([hipcc, *common, *flags, "-c", str(CSRC / unit), "-o", str(obj)])
-    cmds.append([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB_PATH), *objs])
+    cmds.append([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(lib_path), *objs])
     # the three compiles are independent: run them side by side, then link
     procs = []
     for cmd in cmds[:-1]:
@@ -116,9 +118,28 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     proc = subprocess.run(cmds[-1], capture_output=True, text=True)
     if proc.returncode != 0:
         raise RuntimeError(f"hipcc link failed ({proc.returncode}):\n{proc.stdout}\n{proc.stderr}")
-    FLAGS_PATH.write_text(flags_record(extra))
-    return LIB_PATH
+    flags_path.write_text(flags_record(extra))
+    return lib_path
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    """Compile librt_s8.so (or the RT_LIB_VARIANT named) if missing or stale.  Raises on failure (no fallback)."""
+    if not force and not needs_build():
+        return LIB_PATH
+    return _compile(LIB_PATH, FLAGS_PATH, LIB_DIR / (f"obj_{VARIANT}" if VARIANT else "obj"), _extra_flags(), verbose)
+
+
+def build_debug(force: bool = False, verbose: bool = False) -> Path:
+    """Compile the test library lib/librt_s8_dbg.so (product sources + -DRT_DEBUG_HOOKS) if missing or stale."""
+    fp = DEBUG_LIB_PATH.with_suffix(".flags")
+    stale = (not DEBUG_LIB_PATH.exists() or not fp.exists() or fp.read_text() != flags_record(DEBUG_FLAGS)
+             or any(d.stat().st_mtime > DEBUG_LIB_PATH.stat().st_mtime for d in _deps()))
+    if not force and not stale:
+        return DEBUG_LIB_PATH
+    return _compile(DEBUG_LIB_PATH, fp, LIB_DIR / f"obj_{DEBUG_VARIANT}", DEBUG_FLAGS, verbose)
 
 
 if __name__ == "__main__":
     print(build(force=True, verbose=True))
+    if not VARIANT:
+        print(build_debug(force=True, verbose=True))

@@ -23,6 +23,7 @@
 #include <thread>
 #include <vector>
 
+#include "rt_assign.h"
 #include "rt_bvh.h"
 #include "rt_kernel.hip.h"
 #include "rt_tile.h"
@@ -184,6 +185,8 @@ struct rt_scene {
     };
     Ring rings[4];
     uint64_t ring_clock = 0;
+    unsigned long long* d_cost = nullptr;       // per-strip ray segments of the host-buffer batched call (frame context)
+    size_t d_cost_cap = 0;
     // staging for the host-buffer entry point (grown on demand)
     uint8_t* d_out = nullptr;
     size_t d_out_cap = 0;
@@ -265,8 +268,9 @@ bool same_frame(const rt_tile_request& a, const rt_tile_request& b) {
 
 // Enqueue a batch of strips of one frame (<= MAX_BATCH) as ONE launch of persistent waves.
 // Caller holds sc->mu and has the device current.
+// d_strip_cost: optional device array of n counters (zeroed by the caller, on `stream`) that receives the ray segments of every strip.
 int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* const* d_rgb, void* const* d_f32,
-                 hipStream_t stream) {
+                 hipStream_t stream, unsigned long long* d_strip_cost = nullptr) {
     const rt_tile_request* rq = &rqs[0];
     rtk::KParams p;
     std::memset(&p, 0, sizeof p);
@@ -489,7 +493,7 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
         const int forced = dbg(DBG_SLOTS);
         p.n_slots = forced > 0 ? std::min<uint32_t>((uint32_t)forced, rtk::SLOTS_MAX)
                                : (uint32_t)std::min<uint64_t>(rtk::SLOTS_MAX, std::max<uint64_t>(4u, 384u / slot_units));
-        const uint32_t cs = dbg(DBG_COMMIT_SLOTS) > 0 ? (uint32_t)dbg(DBG_COMMIT_SLOTS) : std::max<uint32_t>(1u, p.n_slots * 3u / 8u);
+        const uint32_t cs = dbg(DBG_COMMIT_SLOTS) > 0 ? (uint32_t)dbg(DBG_COMMIT_SLOTS) : std::max<uint32_t>(1u, p.n_slots / 2u);     // (c3: 8 ... 20 of 32 within 0.7 %)
         p.commit_slots = std::min<uint32_t>(cs, p.n_slots);
         // q / d == mulhi(q, floor(2^32 / d) + 1) whenever q * d < 2^32: q < 65 * spp with spp <= RT_MAX_SPP (4096)
         p.spp_magic = p.spp > 1u ? (uint32_t)((1ull << 32) / p.spp) + 1u : 0u;
@@ -510,6 +514,7 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     if (slot >= QUEUE_SLOTS) return fail(RT_ERR_LIMIT, "too many uncollected launches: call rt_scene_collect()");
     p.counters = sc->d_counters;
     p.queue = sc->d_counters + 4 + slot;
+    p.strip_cost = d_strip_cost;
 
     // persistent grid: as many workgroups as the chip holds at this LDS/VGPR budget
     int per_cu = 0;
@@ -1252,6 +1257,7 @@ static int rt_scene_destroy_impl(rt_scene* sc) {
     (void)hipFree(sc->d_counters);
     (void)hipFree(sc->d_out);
     (void)hipFree(sc->d_outf);
+    (void)hipFree(sc->d_cost);
     delete sc;
     g_live_scenes.fetch_sub(1);
     return RT_OK;
@@ -1303,8 +1309,10 @@ static int rt_scene_collect_impl(rt_scene* sc, rt_tile_stats* st) {
     return collect_locked(sc, st);
 }
 
+// strip_cost_out: optional host array of n counters: the ray segments of every strip (frame context)
 static int rt_scene_render_tiles_impl(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, uint8_t* const* out_rgb,
-                                 size_t out_len_each, float* const* out_f32, rt_tile_stats* stats) {
+                                 size_t out_len_each, float* const* out_f32, rt_tile_stats* stats,
+                                 unsigned long long* strip_cost_out = nullptr) {
     if (!sc) return fail(RT_ERR_BAD_ARG, "scene is NULL");
     int rc = check_batch(rqs, n);
     if (rc) return rc;
@@ -1335,6 +1343,16 @@ static int rt_scene_render_tiles_impl(rt_scene* sc, const rt_tile_request* rqs, 
         hipError_t e = hipMalloc(&sc->d_outf, need * n * sizeof(float));
         if (e != hipSuccess) return fail(RT_ERR_OOM, "hipMalloc(strips f32) failed");
         sc->d_outf_cap = need * n * sizeof(float);
+    }
+    if (strip_cost_out) {
+        if (sc->d_cost_cap < n) {
+            (void)hipFree(sc->d_cost);
+            sc->d_cost = nullptr;
+            sc->d_cost_cap = 0;
+            if (hipMalloc(&sc->d_cost, (size_t)n * sizeof(unsigned long long)) != hipSuccess) return fail(RT_ERR_OOM, "hipMalloc(strip costs) failed");
+            sc->d_cost_cap = n;
+        }
+        HIPCHK(hipMemsetAsync(sc->d_cost, 0, (size_t)n * sizeof(unsigned long long), st));
     }
     // settle anything enqueued earlier so the stats of this call are its own
     rt_tile_stats prev;
@@ -1385,7 +1403,8 @@ static int rt_scene_render_tiles_impl(rt_scene* sc, const rt_tile_request* rqs, 
     }
     for (size_t g = 0; g < groups.size(); g++) {
         const uint32_t i0 = groups[g].first, m = groups[g].second;
-        rc = launch_batch(sc, rqs + i0, m, drgb.data() + i0, want_f32 ? df32.data() + i0 : nullptr, st);
+        rc = launch_batch(sc, rqs + i0, m, drgb.data() + i0, want_f32 ? df32.data() + i0 : nullptr, st,
+                          strip_cost_out ? sc->d_cost + i0 : nullptr);
         if (rc) return rc;
         HIPCHK(hipEventRecord(gev[g].a, st));
     }
@@ -1396,6 +1415,7 @@ static int rt_scene_render_tiles_impl(rt_scene* sc, const rt_tile_request* rqs, 
             if (df32[i]) HIPCHK(hipMemcpyAsync(out_f32[i], df32[i], need * sizeof(float), hipMemcpyDeviceToHost, cs));
         }
     }
+    if (strip_cost_out) HIPCHK(hipMemcpyAsync(strip_cost_out, sc->d_cost, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost, cs));
     HIPCHK(hipEventRecord(gev.back().b, cs));
     HIPCHK(hipEventSynchronize(gev.back().b));
     float d2h = 0.f;
@@ -1416,7 +1436,11 @@ static int rt_scene_render_tile_impl(rt_scene* sc, const rt_tile_request* rq, ui
     return rt_scene_render_tiles_impl(sc, rq, 1, rgb, out_len, out_f32 ? f32 : nullptr, stats);
 }
 
-// debug: raw read of the scene's device counter words (tools/phase_census.py); not part of rt_tile.h
+// ---- Test / tool hooks.  NOT part of rt_tile.h and NOT in the product library: compiled only with -DRT_DEBUG_HOOKS, which
+// build.py adds for lib/librt_s8_dbg.so (tests) and tools add to their instrumented variants.  tests/test_abi.py checks that
+// librt_s8.so exports exactly the functions rt_tile.h declares.
+#ifdef RT_DEBUG_HOOKS
+// debug: raw read of the scene's device counter words (tools/phase_census.py)
 extern "C" __attribute__((visibility("default"))) int rt_debug_read_counters(rt_scene* sc, uint32_t first, uint32_t n,
                                                                              unsigned long long* out) {
     return guarded([&]() -> int {
@@ -1456,6 +1480,17 @@ extern "C" __attribute__((visibility("default"))) int rt_debug_set(const char* n
         if (!strcmp(name, g_dbg_spec[k].env)) return g_dbg[k].exchange(value);
     return INT32_MIN;
 }
+// test hook (tests/test_abi.py): throw inside a guarded body; the status comes back, nothing unwinds
+extern "C" __attribute__((visibility("default"))) int rt_debug_throw(int kind) {
+    return guarded([&]() -> int {
+        if (kind == 0) throw std::bad_alloc();
+        if (kind == 1) throw std::runtime_error("rt_debug_throw");
+        if (kind == 2) throw 42;
+        if (kind == 3) { std::vector<char> v; v.reserve((size_t)-1 / 2); }      // a real failed allocation (length_error / bad_alloc)
+        return RT_OK;
+    });
+}
+#endif  // RT_DEBUG_HOOKS
 
 static int rt_render_tile_impl(int device, const rt_tile_request* rq, const rt_sphere* sp, uint32_t ns,
                           const rt_triangle* tr, uint32_t nt, const uint32_t* world_index, uint8_t* out_rgb, size_t out_len,
@@ -1514,6 +1549,14 @@ struct rt_frame_ctx {
     size_t strip = 0;
     bool use_queue = false;
     std::atomic<uint32_t> next_strip{0};
+    // strip assignment (rt_assign.h): owner[k] = entry of strip k for THIS frame; strip_cost = ray segments per strip measured on the
+    // job's last frame (valid while the world and the frame's geometry stay what they were)
+    std::vector<uint32_t> owner;
+    uint32_t assignment = 0;
+    std::vector<double> strip_cost;
+    rt_tile_request cost_rq;            // the frame the costs were measured on
+    bool cost_valid = false;
+    std::vector<unsigned long long> cost_now;   // filled by the dispatchers during a frame (each writes its own strips' entries)
     // the caller's frame buffer, page-locked once
     void* pinned_ptr = nullptr;
     size_t pinned_len = 0;
@@ -1535,16 +1578,25 @@ int frame_dev_render(rt_frame_ctx* fc, int w) {
         // over the slaves): all strips of this device go out as one batch (one launch per <= MAX_BATCH strips, the last
         // quarter as its own launch so that the downloads of the others run under it); stitch by division_no: strip k
         // lands at byte offset k * strip (controller main.rs:109-115)
+        // (which strips: fc->owner, made by rt_frame_ctx_render — snake / longest-first by measured cost / k % nd, rt_assign.h)
         std::vector<rt_tile_request> rqs;
         std::vector<uint8_t*> outs;
-        for (uint32_t k = (uint32_t)w; k < rq0.divisions; k += (uint32_t)nd) {
+        std::vector<uint32_t> mine;
+        for (uint32_t k = 0; k < rq0.divisions; k++) {
+            if (fc->owner[k] != (uint32_t)w) continue;
             rt_tile_request rq = rq0;
             rq.division_no = k;
             rqs.push_back(rq);
             outs.push_back(out_rgb + (size_t)k * strip);
+            mine.push_back(k);
         }
+        (void)nd;
         if (rqs.empty()) return RT_OK;
-        return rt_scene_render_tiles_impl(sc, rqs.data(), (uint32_t)rqs.size(), outs.data(), strip, nullptr, &d.st);
+        std::vector<unsigned long long> cost(rqs.size(), 0ull);
+        int r = rt_scene_render_tiles_impl(sc, rqs.data(), (uint32_t)rqs.size(), outs.data(), strip, nullptr, &d.st, cost.data());
+        if (r) return r;
+        for (size_t i = 0; i < mine.size(); i++) fc->cost_now[mine[i]] = cost[i];      // (disjoint entries per dispatcher)
+        return RT_OK;
     }
     // ---- dynamic assignment: pull one strip at a time, the bottom of the frame first (its strips cost the most:
     // longest-first keeps the devices' finish times within one cheap strip of each other).  Two strips in flight per
@@ -1701,6 +1753,7 @@ int rt_frame_ctx_create_impl(const int* devices, int n_devices, rt_frame_ctx** o
     rt_frame_ctx* fc = new rt_frame_ctx;
     fc->fd.resize(devs.size());
     std::memset(&fc->rq, 0, sizeof fc->rq);
+    std::memset(&fc->cost_rq, 0, sizeof fc->cost_rq);
     size_t started = 0;
     try {
         for (; started < devs.size(); started++) {
@@ -1746,6 +1799,7 @@ int rt_frame_ctx_set_world_impl(rt_frame_ctx* fc, const rt_sphere* sp, uint32_t 
     build_host_scene(sp, ns, tr, nt, world_index, hs);
     fc->hs = &hs;
     fc->have_world = false;
+    fc->cost_valid = false;            // another world: the strips' costs are to be measured again
     rc = frame_run(fc, rt_frame_ctx::CMD_UPLOAD);
     fc->hs = nullptr;
     if (rc) return rc;
@@ -1790,14 +1844,36 @@ int rt_frame_ctx_render_impl(rt_frame_ctx* fc, const rt_tile_request* rq_in, uin
             pin_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
         }
     }
-    rq0.flags &= ~(uint32_t)(RT_FLAG_FRAME_QUEUE | RT_FLAG_FRAME_NO_PIN);   // frame-level: not the kernels' business
+    rq0.flags &= ~(uint32_t)(RT_FLAG_FRAME_QUEUE | RT_FLAG_FRAME_NO_PIN | RT_FLAG_FRAME_STATIC);   // frame-level: not the kernels' business
     fc->rq = rq0;
     fc->out = out_rgb;
     fc->strip = strip;
     fc->use_queue = (rq_in->flags & RT_FLAG_FRAME_QUEUE) != 0;
     fc->next_strip.store(0);
+    // which entry renders which strip (rt_assign.h).  The measured costs hold for the same world and the same frame geometry
+    // (size, strips, samples, depth, camera, t window): the seed changes the paths, not where the expensive rows are.
+    {
+        rt_tile_request a = rq0, b = fc->cost_rq;
+        a.seed = b.seed = 0;
+        a.division_no = b.division_no = 0;
+        a.flags = b.flags = 0;
+        const bool usable = fc->cost_valid && same_frame(a, b) && fc->strip_cost.size() == rq0.divisions;
+        const rtassign::Mode mode = fc->use_queue ? rtassign::QUEUE
+                                    : (rq_in->flags & RT_FLAG_FRAME_STATIC) ? rtassign::STATIC_MOD
+                                    : usable ? rtassign::BY_COST : rtassign::SNAKE;
+        fc->assignment = (uint32_t)mode;
+        rtassign::assign(rq0.divisions, (uint32_t)fc->fd.size(), usable ? fc->strip_cost.data() : nullptr,
+                         mode == rtassign::QUEUE ? rtassign::STATIC_MOD : mode, fc->owner);
+        fc->cost_now.assign(rq0.divisions, 0ull);
+    }
     rc = frame_run(fc, rt_frame_ctx::CMD_RENDER);
     if (rc) return rc;
+    if (!fc->use_queue) {
+        // the strips' costs as this frame measured them: the next frame of the job is assigned by them
+        fc->strip_cost.assign(fc->cost_now.begin(), fc->cost_now.end());
+        fc->cost_rq = rq0;
+        fc->cost_valid = true;
+    }
     rt_frame_stats fs;
     std::memset(&fs, 0, sizeof fs);
     rt_tile_stats& tot = fs.totals;
@@ -1831,6 +1907,17 @@ int rt_frame_ctx_render_impl(rt_frame_ctx* fc, const rt_tile_request* rq_in, uin
     fs.host_ms = fs.wall_ms - fs.pin_ms - fs.kernel_ms - fs.d2h_exposed_ms;
     fs.n_devices = (uint32_t)fc->fd.size();
     fs.pinned = fc->pinned_ptr == (void*)out_rgb ? 1u : 0u;
+    fs.assignment = fc->assignment;
+    {
+        unsigned long long mx = 0, tot = 0;
+        for (size_t e = 0; e < fc->fd.size(); e++) {
+            const unsigned long long sg = fc->fd[e].st.ray_segments;
+            if (e < RT_FRAME_STATS_ENTRIES) fs.entry_segments[e] = sg;
+            mx = std::max(mx, sg);
+            tot += sg;
+        }
+        fs.balance_max_over_mean = tot ? (float)((double)mx * (double)fc->fd.size() / (double)tot) : 0.f;
+    }
     if (stats) *stats = fs;
     return RT_OK;
 }
@@ -1928,12 +2015,12 @@ RT_API int rt_frame_ctx_render(rt_frame_ctx* fc, const rt_tile_request* rq, uint
 }
 RT_API int rt_frame_ctx_release_buffer(rt_frame_ctx* fc) { return guarded([&] { return rt_frame_ctx_release_buffer_impl(fc); }); }
 RT_API void rt_frame_ctx_destroy(rt_frame_ctx* fc) { (void)guarded([&] { return rt_frame_ctx_destroy_impl(fc); }); }
-// debug: the file the library's HIP calls are bound to.  A process may hold two HIP runtimes — PyTorch wheels bundle their own
+// The file the library's HIP calls are bound to (rt_tile.h).  A process may hold two HIP runtimes — PyTorch wheels bundle their own
 // libamdhip64.so (no SONAME), this library asks for ROCm's libamdhip64.so.7 — and the dynamic loader binds this library's hip*
-// symbols to whichever came FIRST in the global scope (profiles/README.md, "two HIP runtimes in one process").  bench.py and
-// the tests use this to create streams with the same runtime and to refuse a process in which torch and the library would
-// drive the device through different ones.  Returns the length of the path (0: unknown).
-extern "C" __attribute__((visibility("default"))) size_t rt_debug_hip_runtime(char* buf, size_t cap) {
+// symbols to whichever came FIRST in the global scope (profiles/README.md, "two HIP runtimes in one process").  A host that makes
+// its own streams or device buffers for the *_device entry points must make them with THIS runtime; the Python mirror uses it to
+// refuse a process in which torch and the library would drive the device through different ones.
+RT_API size_t rt_hip_runtime_path(char* buf, size_t cap) {
     Dl_info info;
     std::memset(&info, 0, sizeof info);
     if (!dladdr(reinterpret_cast<const void*>(&hipGetDeviceCount), &info) || !info.dli_fname) return 0;
@@ -1945,15 +2032,4 @@ extern "C" __attribute__((visibility("default"))) size_t rt_debug_hip_runtime(ch
     }
     return n;
 }
-// test hook (tests/test_abi.py, not part of rt_tile.h): throw inside a guarded body; the status comes back, nothing unwinds
-extern "C" __attribute__((visibility("default"))) int rt_debug_throw(int kind) {
-    return guarded([&]() -> int {
-        if (kind == 0) throw std::bad_alloc();
-        if (kind == 1) throw std::runtime_error("rt_debug_throw");
-        if (kind == 2) throw 42;
-        if (kind == 3) { std::vector<char> v; v.reserve((size_t)-1 / 2); }      // a real failed allocation (length_error / bad_alloc)
-        return RT_OK;
-    });
-}
-
 }  // extern "C"

@@ -124,7 +124,12 @@ constexpr uint32_t STAGE_TILES = 3;               // output staging: tiles a wav
 struct WaveQ {
     uint32_t cnt[SLOTS_MAX];                     // per slot: units not yet finished (0: complete, waiting for its commit; SLOT_FREE: free)
     uint8_t stack[SLOTS_MAX];                    // the free slots, last freed on top (a slot that was just written is reused first: L2)
+    // per-strip cost (KParams::strip_cost): ray segments of this wave since ...
+    unsigned long long cost_last;                //   ... its last tile fetch (the wave's running total then)
+    unsigned long long cost_acc;                 //   segments booked to cost_strip and not yet added to the launch's array
+    uint32_t cost_strip, pad_;                   //   the strip (in the batch) of the tile the wave is issuing from
 };
+static_assert(sizeof(WaveQ) == 184, "WaveQ layout (rt_api.hip: LDS_LIMIT leaves 3 KiB of static LDS)");
 struct WaveStage {                               // kernels with output staging only
     int left[STAGE_TILES + 1];                   // pixels of the staged tile not yet committed (< 0: stage slot free)
     uint32_t dst_lo[STAGE_TILES + 1], dst_hi[STAGE_TILES + 1];   // the tile's first byte in the strip
@@ -203,6 +208,8 @@ struct KParams {
     const uint32_t* leaf_of;     // [n_sph+n_tri] primitive -> leaf node index (= DFS rank)
     const uint32_t* world_rank;  // [n_sph+n_tri] primitive -> position in RenderInfo.world, or nullptr (= primitive order): the
                                  //   tie order of plain linear-scan semantics (RT_FLAG_NO_BVH_CULL)
+    unsigned long long* strip_cost;  // optional [n_strips]: ray segments per strip of the batch (what the frame context balances devices by);
+                                 //   booked by tile: segments the wave traced between two tile fetches go to the tile it left
     unsigned long long* counters;// [0] segments [1] candidates [2] fallbacks
     unsigned long long* queue;   // tile queue head of this launch (zeroed on the stream before it)
     StripDesc strips[MAX_BATCH];
@@ -217,8 +224,6 @@ __device__ __forceinline__ V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b
 __device__ __forceinline__ V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 __device__ __forceinline__ V3 operator*(float s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
 __device__ __forceinline__ V3 operator*(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
-// timing probes (never in a product build, wrong images): the IEEE square roots / divisions of the hot phases as the bare hardware
-// approximations, to price their correction and scaling sequences — -DRT_PROBE_FAST_SQRT, -DRT_PROBE_FAST_DIV
 // sqrtf, correctly rounded as IEEE 754 demands, for less than the compiler's sequence.  That sequence is v_sqrt_f32, two one-ulp
 // residual tests and, around them, a scaling of small operands and a class fix-up: 16 instructions, nine of them in the 4-cycle class
 // (tools/ubench/valu_classes).  Here: v_rsq_f32 and one coupled Newton step — seven fast-class instructions — which gives the
@@ -250,17 +255,18 @@ __device__ __forceinline__ float sqrt_rn(float x) {
     return y;
 #endif
 }
-#ifdef RT_PROBE_FAST_SQRT
-#define RT_SQRT(x_) __builtin_amdgcn_sqrtf(x_)
-#define RT_SQRT_NEG_OK(x_) __builtin_amdgcn_sqrtf(x_)
-#else
 #define RT_SQRT(x_) sqrt_rn(x_)
 #define RT_SQRT_NEG_OK(x_) sqrt_rn<true>(x_)
-#endif
-#ifdef RT_PROBE_FAST_DIV
-#define RT_DIV(a_, b_) ((a_) * __builtin_amdgcn_rcpf(b_))
-#else
 #define RT_DIV(a_, b_) ((a_) / (b_))
+// Hooks of the timing probes (tools/probes/rt_probes.h: extra loads / ALU work per node step, bare hardware sqrt / rcp — some of them
+// render WRONG images by design).  They expand to nothing here; a measurement build adds -DRT_PROBES -Itools/probes, which no product
+// build does (ray_tracer_s8_amd/build.py records every library's flags, bench.py and the tests refuse a non-default record).
+#define RT_HOOK_LT_STEP_LOADS(nd_, ni_, lnodes_)
+#define RT_HOOK_LT_STEP_ALU(p0_, p1_, p2_, p3_, oy_)
+#define RT_HOOK_LT_STEP_END
+#define RT_HOOK_Q_GATHER(t_ref_, cl_, travq_, n_internal_)
+#ifdef RT_PROBES
+#include "rt_probes.h"
 #endif
 __device__ __forceinline__ V3 operator/(V3 a, float s) { return {RT_DIV(a.x, s), RT_DIV(a.y, s), RT_DIV(a.z, s)}; }
 // glam sse2 dot3 order: (x*x' + y*y') + z*z'
@@ -647,6 +653,11 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
             wave_q[threadIdx.x >> 6].cnt[threadIdx.x & 63u] = SLOT_FREE;
             wave_q[threadIdx.x >> 6].stack[threadIdx.x & 63u] = (uint8_t)(p.n_slots - 1u - min(threadIdx.x & 63u, p.n_slots - 1u));
         }
+        if ((threadIdx.x & 63u) == 0u) {
+            wave_q[threadIdx.x >> 6].cost_last = 0ull;
+            wave_q[threadIdx.x >> 6].cost_acc = 0ull;
+            wave_q[threadIdx.x >> 6].cost_strip = 0xffffffffu;
+        }
         (void)z;
         if (CAN_STAGE && (threadIdx.x & 63u) <= STAGE_TILES) wave_st[threadIdx.x >> 6].left[threadIdx.x & 63u] = -1;
     }
@@ -815,21 +826,31 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
     // q / spp for q < 65 * spp (a unit's place in its tile -> its pixel): a multiply-high (spp 1: the unit itself)
     auto div_spp = [&](uint32_t q) -> uint32_t { return p.spp_magic ? __umulhi(q, p.spp_magic) : q; };
 
+    // per-strip cost: the segments this wave traced since its last tile fetch go to the strip it was issuing from; the sum for a
+    // strip travels to the launch's array when the wave moves to another strip (and at its end): a handful of atomics per wave
+    auto book_cost = [&](uint32_t next_strip) {
+        const unsigned long long tot = wave_sum((unsigned long long)n_seg);
+        if (lane == 0) {
+            const unsigned long long last = wq.cost_last;
+            unsigned long long acc = wq.cost_acc + (tot >= last ? tot - last : tot);     // (tot < last: the counters were drained in between)
+            wq.cost_last = tot;
+            const uint32_t cs = wq.cost_strip;
+            if (cs != next_strip) {
+                if (acc && cs != 0xffffffffu) atomicAdd(&p.strip_cost[cs], acc);
+                acc = 0ull;
+                wq.cost_strip = next_strip;
+            }
+            wq.cost_acc = acc;
+        }
+    };
+
     TDECL;
     for (;;) {
         WCOUNT(0);
         TSTAMP(5);
-        // (the cursors are wave-uniform by construction; said once per round so that they live in scalar registers)
-#ifdef X_UNI_TOP
-        sp = uni(sp); cur_slot = uni(cur_slot); tile_u = uni(tile_u); tile_units = uni(tile_units);
-        tile_x0 = uni(tile_x0); tile_row = uni(tile_row); tile_yg = uni(tile_yg); tile_meta = uni(tile_meta);
-        tile_seed = (uint64_t)uni((uint32_t)tile_seed) | ((uint64_t)uni((uint32_t)(tile_seed >> 32)) << 32);
-        q_drained = uni(q_drained ? 1u : 0u) != 0u;
-#endif
+        // (the cursors are wave-uniform by construction; every assignment says so — uni() — so that they live in scalar registers
+        // across the loop: left to the compiler they travelled through vector registers, a dozen moves per round)
         // ================= commit: complete slots -> pixels (main.rs:73-81)
-#ifdef X_MARKS
-        asm volatile("; MARK commit begin");
-#endif
         if (sp != p.n_slots) {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");          // the lanes' deposits of the last round
             const bool slot_done = (uint32_t)lane < SLOTS_MAX && wq.cnt[lane & (int)(SLOTS_MAX - 1u)] == 0u;
@@ -864,19 +885,20 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
                         {
                             // pix_color += (main.rs:75), s = 0 .. spp - 1; the loads of four samples in flight together
                             uint32_t i = 0;
+                            constexpr int CB = 4;            // (eight per trip in the LDS-tree kernel, which has the registers: no difference)
 #pragma clang loop unroll(disable)
-                            for (; i + 4u <= p.spp; i += 4u) {
+                            for (; i + (uint32_t)CB <= p.spp; i += (uint32_t)CB) {
                                 LCOUNT(12);
-                                float c[12];
+                                float c[3 * CB];
 #pragma unroll
-                                for (int e = 0; e < 12; e++) c[e] = __hip_atomic_load(r + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                for (int e = 0; e < 3 * CB; e++) c[e] = __hip_atomic_load(r + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-                                for (int e = 0; e < 4; e++) {
+                                for (int e = 0; e < CB; e++) {
                                     sum_r = sum_r + c[3 * e + 0];
                                     sum_g = sum_g + c[3 * e + 1];
                                     sum_b = sum_b + c[3 * e + 2];
                                 }
-                                r += 12;
+                                r += 3 * CB;
                             }
 #pragma clang loop unroll(disable)
                             for (; i < p.spp; i++) {
@@ -958,9 +980,6 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             }
         }
-#ifdef X_MARKS
-        asm volatile("; MARK commit end");
-#endif
         TSTAMP(6);
         if (TRAVERSE && __ballot(((n_seg | n_cand | n_fall | n_int) & 0x80000000u) != 0)) drain_counters();
         // ================= unit acquisition: lanes without a unit take the next units of the open slot, then of the next free slot
@@ -1031,6 +1050,7 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
                     // decode the tile once, wave-uniformly: strip, tile origin, global row and seed
                     uint32_t tstrip;
                     decode_tile(t, tstrip, tile_x0, tile_row);
+                    if (p.strip_cost) book_cost(tstrip);
                     tile_x0 = uni(tile_x0 + sub);
                     tile_row = uni(tile_row);
                     if (tile_x0 >= p.W) continue;                 // (a quarter beyond the right edge of a ragged tile: nothing in it)
@@ -1121,9 +1141,6 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
             }
         }
         const bool active = have_unit;
-#ifdef X_MARKS
-        asm volatile("; MARK acq end");
-#endif
         TSTAMP(0);
         if (active && need_ray) {
             // ---- next ray of the lane: the camera ray of a new sample (Camera::get_ray, camera.rs:109-129) or the
@@ -1473,50 +1490,10 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
                 const float p0 = fx[0], p1 = fx[1], p2 = fx[3], p3 = fx[4], p4 = fy[0], p5 = fy[1], p6 = fy[3], p7 = fy[4];
                 const float p8 = fz[0], p9 = fz[1], p10 = fz[3], p11 = fz[4];
                 const uint32_t refs = __float_as_uint(nd[18]);
-#ifdef RT_PROBE_LT_LDS64
-                // timing probe: RT_PROBE_LT_LDS64 (1..4) more 8-byte-aligned single ds_read_b64 of the node's neighbourhood per step
-                // (inline asm: the compiler would merge neighbours into ds_read2_b64, which runs at half the rate); consumed
-                // at the end of the step, after the step's own waits
-                typedef float f2_ __attribute__((ext_vector_type(2)));
-                f2_ e0_, e1_, e2_, e3_;
-                {
-                    const uint32_t a_ = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const float*)(lnodes + (ni & ~1u));
-                    asm volatile("ds_read_b64 %0, %1" : "=v"(e0_) : "v"(a_));
-                    if (RT_PROBE_LT_LDS64 > 1) asm volatile("ds_read_b64 %0, %1 offset:8" : "=v"(e1_) : "v"(a_));
-                    if (RT_PROBE_LT_LDS64 > 2) asm volatile("ds_read_b64 %0, %1 offset:16" : "=v"(e2_) : "v"(a_));
-                    if (RT_PROBE_LT_LDS64 > 3) asm volatile("ds_read_b64 %0, %1 offset:24" : "=v"(e3_) : "v"(a_));
-                }
-#endif
-#ifdef RT_PROBE_LT_LDS
-                // timing probe (never in a product build): RT_PROBE_LT_LDS more dword reads of the node per step, results discarded
-                {
-                    float e_[RT_PROBE_LT_LDS];
-#pragma unroll
-                    for (int i = 0; i < RT_PROBE_LT_LDS; i++) e_[i] = nd[(2 + 3 * i) % 18];
-#pragma unroll
-                    for (int i = 0; i < RT_PROBE_LT_LDS; i++) asm volatile("" ::"v"(e_[i]));
-                }
-#endif
+                RT_HOOK_LT_STEP_LOADS(nd, ni, lnodes);
                 // all seven reads in flight before the first use (the scheduler, short of registers, serialised them)
                 __builtin_amdgcn_sched_barrier(0);
-#ifdef RT_PROBE_LT_VALU
-                // timing probe: RT_PROBE_LT_VALU more independent v_add_f32 per step (four chains), results discarded
-                {
-                    float a_[4] = {p0, p1, p2, p3};
-#pragma unroll
-                    for (int i = 0; i < RT_PROBE_LT_VALU; i++) a_[i & 3] = a_[i & 3] + o.y;
-                    asm volatile("" ::"v"(a_[0]), "v"(a_[1]), "v"(a_[2]), "v"(a_[3]));
-                }
-#endif
-#ifdef RT_PROBE_LT_VSLOW
-                // timing probe: RT_PROBE_LT_VSLOW more independent v_max_f32 per step
-                {
-                    float a_[4] = {p0, p1, p2, p3};
-#pragma unroll
-                    for (int i = 0; i < RT_PROBE_LT_VSLOW; i++) a_[i & 3] = __builtin_fmaxf(a_[i & 3], a_[(i + 1) & 3]);
-                    asm volatile("" ::"v"(a_[0]), "v"(a_[1]), "v"(a_[2]), "v"(a_[3]));
-                }
-#endif
+                RT_HOOK_LT_STEP_ALU(p0, p1, p2, p3, o.y);
                 const float lxn = (p0 - o.x) * aux.inv.x, lxf = (p1 - o.x) * aux.inv.x;
                 const float rxn = (p2 - o.x) * aux.inv.x, rxf = (p3 - o.x) * aux.inv.x;
                 const float lyn = (p4 - o.y) * aux.inv.y, lyf = (p5 - o.y) * aux.inv.y;
@@ -1542,13 +1519,7 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
                 top_a += delta;
                 if (SLOW) top_a = max(top_a, stack0_a);          // (DONE may pop here: see above)
                 cnt_m += leaf_slot;
-#ifdef RT_PROBE_LT_LDS64
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                asm volatile("" ::"v"(e0_));
-                if (RT_PROBE_LT_LDS64 > 1) asm volatile("" ::"v"(e1_));
-                if (RT_PROBE_LT_LDS64 > 2) asm volatile("" ::"v"(e2_));
-                if (RT_PROBE_LT_LDS64 > 3) asm volatile("" ::"v"(e3_));
-#endif
+                RT_HOOK_LT_STEP_END;
             };
             for (;;) {
                 const uint32_t walking = (uint32_t)__builtin_popcountll(__ballot(in_trav));
@@ -1711,21 +1682,7 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
                             // line in flight — costs 7 % on c5: the step's latency matters more than the texture path's time)
                             cl = qb.z;
                             cr = qb.w;
-#ifdef RT_PROBE_EXTRA_GATHER
-                            // timing probe (never in a product build; tools/ab.sh): RT_PROBE_EXTRA_GATHER more
-                            // 16-byte gathers per node step, n > 0: the same node again (same line), n < 0: another node's line
-                            {
-                                uint32_t zero = 0;
-                                asm volatile("" : "+v"(zero));
-                                for (int e = 0; e < (RT_PROBE_EXTRA_GATHER > 0 ? RT_PROBE_EXTRA_GATHER : -RT_PROBE_EXTRA_GATHER); e++) {
-                                    const uint32_t other = RT_PROBE_EXTRA_GATHER > 0 ? t_ref : ((t_ref + 1u + e) * 2654435761u) % p.n_internal;
-                                    const uint4* nx = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.travq) + (other << 5));
-                                    asm volatile("" : "+v"(nx));
-                                    uint4 qx = nx[0];
-                                    cl ^= qx.x & zero;
-                                }
-                            }
-#endif
+                            RT_HOOK_Q_GATHER(t_ref, cl, p.travq, p.n_internal);
                             if (qfin) {
                                 // slab test in grid units: t = fma(q, ig, cq), the same real value as
                                 // ((base + q*step) - o) * inv up to < 0.15 grid unit of rounding; the boxes carry >= 1 grid
@@ -2073,6 +2030,7 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
         TSTAMP(4);
     }
 
+    if (p.strip_cost) book_cost(0xffffffffu);
     drain_counters();
     TFLUSH;
 #undef wq

@@ -94,17 +94,20 @@ class ImageSlice:
     stats: Optional[TileStats] = None
 
 
-_initialised = False
+_initialised_libs = set()                    # (the product library, and the test library where a test swapped it in)
+
+
+def _is_initialised() -> bool:
+    return id(_abi.load()) in _initialised_libs
 
 
 def init() -> int:
     """rt_init(); returns the device count.  Raises RtError(RT_ERR_NO_DEVICE) without a GPU."""
-    global _initialised
     lib = _abi.load()
     n = C.c_int(0)
     _abi.check(lib.rt_init(C.byref(n)), "rt_init")
     _abi.check_single_hip_runtime()          # torch imported after the library was bound to ROCm's runtime: say so now
-    _initialised = True
+    _initialised_libs.add(id(lib))
     return n.value
 
 
@@ -113,7 +116,7 @@ class Scene:
 
     def __init__(self, device: int, world: World):
         self._lib = _abi.load()
-        if not _initialised:
+        if not _is_initialised():
             init()
         self.world = world
         self.device = device
@@ -271,7 +274,7 @@ class FrameContext:
 
     def __init__(self, devices: Optional[Sequence[int]] = None, world: Optional[World] = None):
         self._lib = _abi.load()
-        if not _initialised:
+        if not _is_initialised():
             init()
         if devices is None:
             dv, nd = None, 0
@@ -281,6 +284,7 @@ class FrameContext:
         _abi.check(self._lib.rt_frame_ctx_create(dv, nd, C.byref(h)), "rt_frame_ctx_create")
         self._h = h
         self._buf = None
+        self._pinned = None                  # the array whose page-locked registration the context holds (kept alive here)
         if world is not None:
             self.set_world(world)
 
@@ -300,19 +304,30 @@ class FrameContext:
             out = self._buf
         if out.dtype != np.uint8 or out.size < n or not out.flags.c_contiguous:
             raise ValueError("out: need a contiguous uint8 array of at least H*W*3 bytes")
+        # rt_tile.h: "the caller must not free a buffer the context still holds".  The context recognises a registered buffer by
+        # its ADDRESS, and a freed array's address may come back with the next allocation — over pages that are no longer the
+        # registered ones.  So the wrapper keeps the registered array alive (self._pinned) and drops the registration BEFORE
+        # another array takes its place.
+        if self._pinned is not None and self._pinned is not out:
+            self.release_buffer()
         fs = FrameStats()
-        _abi.check(self._lib.rt_frame_ctx_render(self._h, C.byref(req), out.ctypes.data_as(C.c_void_p), out.size,
-                                                 C.byref(fs)), "rt_frame_ctx_render")
+        try:
+            _abi.check(self._lib.rt_frame_ctx_render(self._h, C.byref(req), out.ctypes.data_as(C.c_void_p), out.size,
+                                                     C.byref(fs)), "rt_frame_ctx_render")
+        finally:
+            self._pinned = out               # (registered or not: harmless to hold, and an error return may have left it registered)
         return out.reshape(-1)[:n].reshape(req.height, req.width, 3), fs
 
     def release_buffer(self):
         _abi.check(self._lib.rt_frame_ctx_release_buffer(self._h), "rt_frame_ctx_release_buffer")
+        self._pinned = None
 
     def close(self):
         if getattr(self, "_h", None):
             self._lib.rt_frame_ctx_destroy(self._h)      # (drops the registration before the buffer can go away)
             self._h = None
             self._buf = None
+            self._pinned = None
 
     __del__ = close
 
@@ -326,7 +341,7 @@ class FrameContext:
 def render_frame_native(world: World, req: TileRequest, devices: Optional[Sequence[int]] = None):
     """rt_render_frame: the one-shot form of FrameContext (create, set world, one frame, destroy)."""
     lib = _abi.load()
-    if not _initialised:
+    if not _is_initialised():
         init()
     n = req.width * req.height * 3
     out = np.empty(n, np.uint8)

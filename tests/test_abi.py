@@ -2,6 +2,7 @@
 calls: this container has no GPU), argument checks that need no device, struct layouts."""
 import ctypes as C
 import re
+import subprocess
 from pathlib import Path
 
 import numpy as np
@@ -31,7 +32,25 @@ def test_library_exports_every_declared_symbol():
     lib = _abi.load()
     for name in declared_functions():
         assert hasattr(lib, name), f"{name} declared in rt_tile.h but not exported by librt_s8.so"
-    assert lib.rt_abi_version() == 3 == _abi.RT_ABI_VERSION
+    assert lib.rt_abi_version() == 4 == _abi.RT_ABI_VERSION
+
+
+def _exported(path):
+    out = subprocess.run(["nm", "-D", "--defined-only", str(path)], capture_output=True, text=True, check=True).stdout
+    return {ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("rt_")}
+
+
+def test_product_library_exports_exactly_the_header():
+    """`nm -D librt_s8.so`: the rt_* functions of rt_tile.h and nothing else — no rt_debug_* hook (those live in the test
+    library lib/librt_s8_dbg.so, the same sources compiled with -DRT_DEBUG_HOOKS)."""
+    from ray_tracer_s8_amd import build
+    _abi.load()
+    assert _exported(build.LIB_PATH) == set(declared_functions())
+    _abi.load_debug()
+    dbg = _exported(build.DEBUG_LIB_PATH)
+    assert set(declared_functions()) < dbg
+    assert {n for n in dbg if n.startswith("rt_debug_")} == {"rt_debug_read_counters", "rt_debug_sqrt_selftest", "rt_debug_set",
+                                                              "rt_debug_throw"}
 
 
 def test_abi_version_is_one_number_everywhere():
@@ -53,7 +72,8 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_abi.TileRequest) == 64
     assert _abi.SPHERE_DTYPE.itemsize == 36 and _abi.TRIANGLE_DTYPE.itemsize == 56
     assert C.sizeof(_abi.TileStats) == 64
-    assert C.sizeof(_abi.FrameStats) == 96 and _abi.FrameStats.wall_ms.offset == 64 and _abi.FrameStats.pinned.offset == 92
+    assert C.sizeof(_abi.FrameStats) == 232 and _abi.FrameStats.wall_ms.offset == 64 and _abi.FrameStats.pinned.offset == 92
+    assert _abi.FrameStats.assignment.offset == 96 and _abi.FrameStats.entry_segments.offset == 104
     offs = {n: getattr(_abi.TileRequest, n).offset for n, _ in _abi.TileRequest._fields_}
     assert offs["width"] == 0 and offs["spp"] == 16 and offs["aperture"] == 24 and offs["seed"] == 48 and offs["flags"] == 56
 
@@ -158,7 +178,7 @@ def test_header_is_valid_c99_and_c_client_links(tmp_path):
 def test_nothing_unwinds_across_the_boundary():
     """rt_tile.h: "never throws or aborts across the boundary".  Every exported entry point runs its body through one
     guard (rt_api.hip: guarded()); rt_debug_throw raises inside such a body — the status comes back, with a message."""
-    lib = _abi.load()
+    lib = _abi.load_debug()                  # (same sources, same guard; the hook that throws exists in the test library only)
     lib.rt_debug_throw.restype = C.c_int
     lib.rt_debug_throw.argtypes = [C.c_int]
     lib.rt_last_error.restype = C.c_char_p
@@ -279,3 +299,43 @@ def test_two_hip_runtimes_in_one_process_are_refused():
                 "except RuntimeError as e:\n    print('REFUSED', 'two HIP runtimes' in str(e), p)")
     r = subprocess.run([sys.executable, "-c", code_bad], capture_output=True, text=True, cwd=str(ROOT), timeout=300)
     assert r.returncode == 0 and "REFUSED True" in r.stdout and "/opt/rocm" in r.stdout, r.stdout + r.stderr
+
+
+def test_frame_context_wrapper_releases_a_registration_before_switching_buffers():
+    """interface.FrameContext against a recording stand-in for the library (no GPU): the array handed to rt_frame_ctx_render
+    stays referenced by the wrapper, and rt_frame_ctx_release_buffer is called BEFORE a different array is passed —
+    including the context's own buffer being replaced when the frame size changes."""
+    from ray_tracer_s8_amd import interface
+
+    calls = []
+
+    class FakeLib:
+        def rt_frame_ctx_render(self, h, rq, ptr, n, fs):
+            calls.append(("render", C.cast(ptr, C.c_void_p).value))
+            return 0
+
+        def rt_frame_ctx_release_buffer(self, h):
+            calls.append(("release",))
+            return 0
+
+        def rt_frame_ctx_destroy(self, h):
+            calls.append(("destroy",))
+
+    fc = interface.FrameContext.__new__(interface.FrameContext)
+    fc._lib, fc._h, fc._buf, fc._pinned = FakeLib(), C.c_void_p(1), None, None
+    rq = _abi.default_request(width=8, height=4, divisions=2, spp=1)
+    a = np.zeros(8 * 4 * 3, np.uint8)
+    fc.render(rq, out=a)
+    fc.render(rq, out=a)
+    assert [c[0] for c in calls] == ["render", "render"] and fc._pinned is a          # same array: registration kept
+    b = np.zeros(8 * 4 * 3, np.uint8)
+    fc.render(rq, out=b)
+    assert [c[0] for c in calls[2:]] == ["release", "render"] and fc._pinned is b     # a stays alive until the release
+    fc.render(rq)                                                                      # the context's own buffer
+    own = fc._buf
+    assert [c[0] for c in calls[4:]] == ["release", "render"] and fc._pinned is own
+    rq2 = _abi.default_request(width=16, height=4, divisions=2, spp=1)
+    fc.render(rq2)                                                                     # frame size changes: a new own buffer
+    assert [c[0] for c in calls[6:]] == ["release", "render"] and fc._pinned is fc._buf and fc._buf is not own
+    fc.close()
+    assert calls[-1] == ("destroy",) and fc._pinned is None

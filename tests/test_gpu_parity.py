@@ -497,19 +497,89 @@ def test_frame_context_reuses_everything_across_frames(ndev, oracle):
         fc.release_buffer()
 
 
+def test_frame_context_balances_entries_by_measured_strip_cost(ndev, oracle):
+    """rt_frame_ctx's strip assignment (rt_assign.h) at eight entries on the one device: frame 1 of a job goes out in snake order,
+    the kernels count every strip's ray segments, frame 2 is assigned longest-first by them; RT_FLAG_FRAME_STATIC keeps k % n.
+    Same bytes whatever the assignment; the per-entry segment counts add up to the frame's; the measured balance improves
+    on the static split's for a frame whose bottom rows cost more than its top rows (c3's scene)."""
+    sph, rq = _small("c3", 320, 256, spp=4, div=32)
+    one = rq.copy()
+    one.divisions = 1
+    want, _, info = oracle.render(one, sph, backend=1)
+    with rt.FrameContext(devices=[0] * 8, world=rt.World(sph)) as fc:
+        seen = {}
+        for name, fl in (("static", _abi.RT_FLAG_FRAME_STATIC), ("first", 0), ("second", 0), ("third", 0), ("static2", _abi.RT_FLAG_FRAME_STATIC)):
+            r = rq.copy()
+            r.flags = fl
+            img, fs = fc.render(r)
+            assert np.array_equal(img.reshape(-1), want), name
+            per = list(fs.entry_segments)[:8]
+            assert sum(per) == fs.totals.ray_segments == info["ray_segments"]
+            assert abs(fs.balance_max_over_mean - max(per) * 8 / sum(per)) < 1e-5
+            seen[name] = (int(fs.assignment), fs.balance_max_over_mean)
+        # (the static frame measured the costs too: the first default frame after it is already assigned by them)
+        assert seen["static"][0] == 0 and seen["static2"][0] == 0
+        assert seen["first"][0] == 2 and seen["second"][0] == 2 and seen["third"][0] == 2
+        # (tiny strips here — 8 rows, 5 tiles — and four of them per entry: bench.py reports the balance of c4 / c5 at full size)
+        assert seen["second"][1] < seen["static"][1] and seen["second"][1] < 1.05, seen
+        # another world: costs are forgotten, the next frame is a snake frame again
+        sph2 = scenes.cornell16()
+        fc.set_world(rt.World(sph2))
+        img, fs = fc.render(rq)
+        assert fs.assignment == 1 and np.array_equal(img.reshape(-1), oracle.render(one, sph2, backend=1)[0])
+        img, fs = fc.render(rq)
+        assert fs.assignment == 2
+        # another frame geometry: measured again as well
+        r = rq.copy()
+        r.spp = 2
+        img, fs = fc.render(r)
+        assert fs.assignment == 1
+
+
+def test_frame_context_outlives_the_buffers_it_was_given(ndev, oracle):
+    """Round-3 advisor: the context keeps the frame buffer page-locked after the call and recognises it by ADDRESS; a numpy
+    array that was dropped and whose address the next allocation takes again must not inherit the stale registration.  The
+    wrapper keeps the registered array alive and releases the registration before another array takes its place."""
+    sph, rq = _small("c3", 192, 96, spp=2, div=4)
+    one = rq.copy()
+    one.divisions = 1
+    n = 192 * 96 * 3
+    with rt.FrameContext(devices=[0], world=rt.World(sph)) as fc:
+        for seed in range(6):
+            r = rq.copy()
+            r.seed = seed
+            tmp = np.empty(n, np.uint8)                       # a temporary: dropped at the end of the iteration
+            img, fs = fc.render(r, out=tmp)
+            assert fs.pinned == 1 and fs.pin_ms > 0           # a NEW registration every time: never a stale one by address
+            o = one.copy()
+            o.seed = seed
+            assert np.array_equal(img.reshape(-1), oracle.render(o, sph, backend=1)[0])
+            assert fc._pinned is tmp
+            del img, tmp
+        own, fs = fc.render(rq)                               # then the context's own buffer, and a change of frame size
+        assert fs.pinned == 1
+        big = rq.copy()
+        big.width, big.height = 256, 128
+        img, fs = fc.render(big)
+        ob = big.copy()
+        ob.divisions = 1
+        assert fs.pinned == 1 and fs.pin_ms > 0 and np.array_equal(img.reshape(-1), oracle.render(ob, sph, backend=1)[0])
+
+
 @pytest.mark.parametrize("cull", [0, _abi.RT_FLAG_CULL_WALK])
 def test_capped_stack_launches_on_two_streams(ndev, oracle, cull):
     """The capped-stack walk (stack entries beyond a few LDS slots live in one per-scene HBM area) enqueued on two
     streams at once: the library chains such launches, so frames rendered 'concurrently' are still exact.  Both the plain
     and the culled walk have a capped-stack variant."""
-    rt.init()
-    hip = _abi.hip_runtime()                 # the runtime the library is bound to (never a second one: profiles/README.md)
-    prev = [_abi.debug_set("RT_FORCE_CAPPED", 1), _abi.debug_set("RT_STACK_LDS", 3)]
-    try:
-        _capped_two_streams(hip, oracle, cull)
-    finally:
-        _abi.debug_set("RT_FORCE_CAPPED", prev[0])
-        _abi.debug_set("RT_STACK_LDS", prev[1])
+    with _abi.debug_library():               # (the knobs are hooks of the TEST library: the product library exports none)
+        rt.init()
+        hip = _abi.hip_runtime()             # the runtime the library is bound to (never a second one: profiles/README.md)
+        prev = [_abi.debug_set("RT_FORCE_CAPPED", 1), _abi.debug_set("RT_STACK_LDS", 3)]
+        try:
+            _capped_two_streams(hip, oracle, cull)
+        finally:
+            _abi.debug_set("RT_FORCE_CAPPED", prev[0])
+            _abi.debug_set("RT_STACK_LDS", prev[1])
 
 
 def _capped_two_streams(hip, oracle, cull):
@@ -1023,7 +1093,7 @@ def test_sqrt_rn_is_the_ieee_square_root_on_every_f32(ndev):
     """sqrt_rn (rt_kernel.hip.h: v_rsq_f32 + one coupled Newton step, the compiler's sequence for the operands outside its
     domain) against __builtin_sqrtf on the device, all 2^32 bit patterns — negative, NaN, zero, subnormal and infinite ones
     included — in both of its forms.  The oracle's sqrtf is the CPU's IEEE one; the committed golden vectors tie the two together."""
-    lib = _abi.load()
+    lib = _abi.load_debug()                  # (a hook of the test library, compiled from the same kernel header)
     lib.rt_debug_sqrt_selftest.restype = C.c_int
     lib.rt_debug_sqrt_selftest.argtypes = [C.c_int, C.c_uint32, C.c_ulonglong, C.POINTER(C.c_ulonglong)]
     total = 0

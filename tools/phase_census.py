@@ -6,7 +6,7 @@ sys.path.insert(0, ".")
 os.environ["RT_LIB_VARIANT"] = "pcensus" + os.environ.get("RT_PT_TAG", "")
 from ray_tracer_s8_amd import build
 if not build.LIB_PATH.exists() or os.environ.get("RT_PT_FLAGS") is not None:
-    os.environ["RT_EXTRA_HIPCC_FLAGS"] = "-DRT_PROFILE_PHASES " + os.environ.get("RT_PT_FLAGS", "")
+    os.environ["RT_EXTRA_HIPCC_FLAGS"] = "-DRT_PROFILE_PHASES -DRT_DEBUG_HOOKS " + os.environ.get("RT_PT_FLAGS", "")
     build.build(force=True)
     del os.environ["RT_EXTRA_HIPCC_FLAGS"]
 import numpy as np

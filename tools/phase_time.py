@@ -7,7 +7,7 @@ sys.path.insert(0, ".")
 os.environ["RT_LIB_VARIANT"] = "ptime" + os.environ.get("RT_PT_TAG", "")
 from ray_tracer_s8_amd import build
 if not build.LIB_PATH.exists() or os.environ.get("RT_PT_FLAGS") is not None:
-    os.environ["RT_EXTRA_HIPCC_FLAGS"] = "-DRT_PROFILE_TIME " + os.environ.get("RT_PT_FLAGS", "")
+    os.environ["RT_EXTRA_HIPCC_FLAGS"] = "-DRT_PROFILE_TIME -DRT_DEBUG_HOOKS " + os.environ.get("RT_PT_FLAGS", "")
     build.build(force=True)
     del os.environ["RT_EXTRA_HIPCC_FLAGS"]
 import ray_tracer_s8_amd as rt
