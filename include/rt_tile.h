@@ -295,7 +295,9 @@ RT_API int rt_scene_collect(rt_scene* scene, rt_tile_stats* stats);
  * in even rows of n strips, to n-1 - k % n in odd ones: every entry gets one strip of each row, which evens out any cost
  * profile that is close to linear in the strip's position — and the kernels count the ray segments of every strip; every
  * later frame of the job (same world, same frame geometry) is assigned LONGEST-FIRST by those counts, each strip to the
- * entry with the least load so far.  All strips of an entry go out in one launch (above 64 MiB of pixels per device: two,
+ * entry with the least load so far.  For these two assignments the context cuts the frame into its own strips — at least
+ * six per entry, whole rows, the next count from max(divisions, 6 n) up that divides the height — since `divisions` is the
+ * reference's wire format, not a property of the image: every cut into whole rows renders the same bytes (`seed` above).  All strips of an entry go out in one launch (above 64 MiB of pixels per device: two,
  * the last quarter of the strips running under the downloads of the rest).  RT_FLAG_FRAME_STATIC in req->flags: the plain
  * split strip k -> devices[k % n]; RT_FLAG_FRAME_QUEUE: the devices pull strips one at a time, bottom of the frame first,
  * two launches in flight per device.  The RGB8 strips are stitched by division_no into out_rgb (H*W*3).  Same bytes

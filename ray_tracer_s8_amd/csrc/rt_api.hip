@@ -97,12 +97,13 @@ enum DebugKnob {
     DBG_VERBOSE,           // RT_VERBOSE         engine / LDS plan of every launch on stderr                 (default 0)
     DBG_REORDER,           // RT_REORDER         0: primitive records stay in the caller's order (A/B)          (default 1)
     DBG_TAIL_TILES,        // RT_TAIL_TILES      tiles at the end of a launch's queue handed out in quarters; -1: host rule (default -1)
+    DBG_STRIP_COST,        // RT_STRIP_COST      0: the kernels do not count per-strip ray segments for the frame context (A/B)   (default 1)
     DBG_N
 };
 std::atomic<int> g_dbg[DBG_N];
 const struct { const char* env; int def; } g_dbg_spec[DBG_N] = {
     {"RT_LDS_TREE", 1}, {"RT_CULL_WALK", -1}, {"RT_NO_STAGE", 0}, {"RT_SLOTS", 0}, {"RT_FORCE_CAPPED", 0},
-    {"RT_STACK_LDS", 0}, {"RT_COMPACT", 1}, {"RT_REFILL_EIGHTHS", 0}, {"RT_COMMIT_SLOTS", 0}, {"RT_VERBOSE", 0}, {"RT_REORDER", 1}, {"RT_TAIL_TILES", -1}};
+    {"RT_STACK_LDS", 0}, {"RT_COMPACT", 1}, {"RT_REFILL_EIGHTHS", 0}, {"RT_COMMIT_SLOTS", 0}, {"RT_VERBOSE", 0}, {"RT_REORDER", 1}, {"RT_TAIL_TILES", -1}, {"RT_STRIP_COST", 1}};
 std::once_flag g_dbg_once;
 void dbg_load_env() {
     std::call_once(g_dbg_once, [] {
@@ -268,7 +269,8 @@ bool same_frame(const rt_tile_request& a, const rt_tile_request& b) {
 
 // Enqueue a batch of strips of one frame (<= MAX_BATCH) as ONE launch of persistent waves.
 // Caller holds sc->mu and has the device current.
-// d_strip_cost: optional device array of n counters (zeroed by the caller, on `stream`) that receives the ray segments of every strip.
+// d_strip_cost: optional device array of COST_COPIES x MAX_BATCH counters (zeroed by the caller, on `stream`): the kernels add the ray
+// segments of strip i of the batch to [copy][i] (KParams::strip_cost); the caller sums the copies.
 int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* const* d_rgb, void* const* d_f32,
                  hipStream_t stream, unsigned long long* d_strip_cost = nullptr) {
     const rt_tile_request* rq = &rqs[0];
@@ -514,7 +516,7 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     if (slot >= QUEUE_SLOTS) return fail(RT_ERR_LIMIT, "too many uncollected launches: call rt_scene_collect()");
     p.counters = sc->d_counters;
     p.queue = sc->d_counters + 4 + slot;
-    p.strip_cost = d_strip_cost;
+    p.strip_cost = dbg(DBG_STRIP_COST) ? d_strip_cost : nullptr;
 
     // persistent grid: as many workgroups as the chip holds at this LDS/VGPR budget
     int per_cu = 0;
@@ -1344,15 +1346,18 @@ static int rt_scene_render_tiles_impl(rt_scene* sc, const rt_tile_request* rqs, 
         if (e != hipSuccess) return fail(RT_ERR_OOM, "hipMalloc(strips f32) failed");
         sc->d_outf_cap = need * n * sizeof(float);
     }
+    // per-strip costs: one block of COST_COPIES x MAX_BATCH counters per launch group of the call
+    constexpr size_t COST_BLOCK = (size_t)rtk::COST_COPIES * rtk::MAX_BATCH;
+    const size_t cost_blocks = strip_cost_out ? (n + rtk::MAX_BATCH - 1) / rtk::MAX_BATCH + 1 : 0;
     if (strip_cost_out) {
-        if (sc->d_cost_cap < n) {
+        if (sc->d_cost_cap < cost_blocks * COST_BLOCK) {
             (void)hipFree(sc->d_cost);
             sc->d_cost = nullptr;
             sc->d_cost_cap = 0;
-            if (hipMalloc(&sc->d_cost, (size_t)n * sizeof(unsigned long long)) != hipSuccess) return fail(RT_ERR_OOM, "hipMalloc(strip costs) failed");
-            sc->d_cost_cap = n;
+            if (hipMalloc(&sc->d_cost, cost_blocks * COST_BLOCK * sizeof(unsigned long long)) != hipSuccess) return fail(RT_ERR_OOM, "hipMalloc(strip costs) failed");
+            sc->d_cost_cap = cost_blocks * COST_BLOCK;
         }
-        HIPCHK(hipMemsetAsync(sc->d_cost, 0, (size_t)n * sizeof(unsigned long long), st));
+        HIPCHK(hipMemsetAsync(sc->d_cost, 0, cost_blocks * COST_BLOCK * sizeof(unsigned long long), st));
     }
     // settle anything enqueued earlier so the stats of this call are its own
     rt_tile_stats prev;
@@ -1404,7 +1409,7 @@ static int rt_scene_render_tiles_impl(rt_scene* sc, const rt_tile_request* rqs, 
     for (size_t g = 0; g < groups.size(); g++) {
         const uint32_t i0 = groups[g].first, m = groups[g].second;
         rc = launch_batch(sc, rqs + i0, m, drgb.data() + i0, want_f32 ? df32.data() + i0 : nullptr, st,
-                          strip_cost_out ? sc->d_cost + i0 : nullptr);
+                          strip_cost_out ? sc->d_cost + g * COST_BLOCK : nullptr);
         if (rc) return rc;
         HIPCHK(hipEventRecord(gev[g].a, st));
     }
@@ -1415,9 +1420,20 @@ static int rt_scene_render_tiles_impl(rt_scene* sc, const rt_tile_request* rqs, 
             if (df32[i]) HIPCHK(hipMemcpyAsync(out_f32[i], df32[i], need * sizeof(float), hipMemcpyDeviceToHost, cs));
         }
     }
-    if (strip_cost_out) HIPCHK(hipMemcpyAsync(strip_cost_out, sc->d_cost, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost, cs));
+    std::vector<unsigned long long> cost_raw;
+    if (strip_cost_out) {
+        cost_raw.resize(groups.size() * COST_BLOCK);
+        HIPCHK(hipMemcpyAsync(cost_raw.data(), sc->d_cost, cost_raw.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, cs));
+    }
     HIPCHK(hipEventRecord(gev.back().b, cs));
     HIPCHK(hipEventSynchronize(gev.back().b));
+    if (strip_cost_out)
+        for (size_t g = 0; g < groups.size(); g++)
+            for (uint32_t i = 0; i < groups[g].second; i++) {
+                unsigned long long sum = 0;
+                for (uint32_t c = 0; c < rtk::COST_COPIES; c++) sum += cost_raw[g * COST_BLOCK + (size_t)c * rtk::MAX_BATCH + i];
+                strip_cost_out[groups[g].first + i] = sum;
+            }
     float d2h = 0.f;
     HIPCHK(hipEventElapsedTime(&d2h, gev.back().a, gev.back().b));   // last launch done -> last byte on the host
     ev_return.ok = true;
@@ -1845,10 +1861,24 @@ int rt_frame_ctx_render_impl(rt_frame_ctx* fc, const rt_tile_request* rq_in, uin
         }
     }
     rq0.flags &= ~(uint32_t)(RT_FLAG_FRAME_QUEUE | RT_FLAG_FRAME_NO_PIN | RT_FLAG_FRAME_STATIC);   // frame-level: not the kernels' business
+    fc->use_queue = (rq_in->flags & RT_FLAG_FRAME_QUEUE) != 0;
+    // The balanced assignments cut the frame into their OWN strips: at least six per entry, so that longest-first has something to
+    // even out with (c5's 16 strips are two per entry at 8 devices: 3 % off the mean at best).  `divisions` is the reference's wire
+    // format, not a property of the image: every sample's stream is keyed by its pixel's place in the FRAME (rt_tile.h `seed`), so
+    // any cut into whole rows gives the same bytes.  The strip queue and RT_FLAG_FRAME_STATIC keep the request's strips.
+    size_t istrip = strip;
+    if (!fc->use_queue && !(rq_in->flags & RT_FLAG_FRAME_STATIC) && fc->fd.size() > 1) {
+        const uint32_t want = std::max<uint32_t>(rq0.divisions, 6u * (uint32_t)fc->fd.size());
+        for (uint32_t dv = want; dv <= std::min<uint32_t>(rq0.height, 4u * want); dv++)
+            if (rq0.height % dv == 0) {
+                rq0.divisions = dv;
+                istrip = rt_tile_bytes(&rq0);
+                break;
+            }
+    }
     fc->rq = rq0;
     fc->out = out_rgb;
-    fc->strip = strip;
-    fc->use_queue = (rq_in->flags & RT_FLAG_FRAME_QUEUE) != 0;
+    fc->strip = istrip;
     fc->next_strip.store(0);
     // which entry renders which strip (rt_assign.h).  The measured costs hold for the same world and the same frame geometry
     // (size, strips, samples, depth, camera, t window): the seed changes the paths, not where the expensive rows are.

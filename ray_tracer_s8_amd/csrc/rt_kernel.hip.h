@@ -122,14 +122,17 @@ constexpr uint32_t SLOTS_MAX = 32;                // pixel slots per wave
 constexpr uint32_t SLOT_FREE = 0x80000000u;       // counter value of a free slot
 constexpr uint32_t STAGE_TILES = 3;               // output staging: tiles a wave may have open
 struct WaveQ {
-    uint32_t cnt[SLOTS_MAX];                     // per slot: units not yet finished (0: complete, waiting for its commit; SLOT_FREE: free)
+    uint32_t cnt[SLOTS_MAX];                     // per slot: bits 0-12 units not yet finished (0: complete, waiting for its commit), bits 13-30 the ray
+                                                 //   segments its finished units traced (per-strip cost), bit 31 = SLOT_FREE
     uint8_t stack[SLOTS_MAX];                    // the free slots, last freed on top (a slot that was just written is reused first: L2)
-    // per-strip cost (KParams::strip_cost): ray segments of this wave since ...
-    unsigned long long cost_last;                //   ... its last tile fetch (the wave's running total then)
-    unsigned long long cost_acc;                 //   segments booked to cost_strip and not yet added to the launch's array
-    uint32_t cost_strip, pad_;                   //   the strip (in the batch) of the tile the wave is issuing from
+    // per-strip cost (KParams::strip_cost): ray segments of committed slots not yet added to the launch's array, for TWO strips — [0] the
+    // one the wave issues from, [1] the one before it (slots of both are in flight when the wave crosses a strip boundary)
+    uint32_t cost_acc[2];
+    uint32_t cost_strip[2];
 };
-static_assert(sizeof(WaveQ) == 184, "WaveQ layout (rt_api.hip: LDS_LIMIT leaves 3 KiB of static LDS)");
+static_assert(sizeof(WaveQ) == 176, "WaveQ layout (rt_api.hip: LDS_LIMIT leaves 3 KiB of static LDS)");
+constexpr uint32_t COST_COPIES = 16;
+constexpr uint32_t SLOT_UNIT_BITS = 13;           // units of a slot < 2^13 (spp <= RT_MAX_SPP = 4096), segments of a slot < 2^18 (x 63 bounces)
 struct WaveStage {                               // kernels with output staging only
     int left[STAGE_TILES + 1];                   // pixels of the staged tile not yet committed (< 0: stage slot free)
     uint32_t dst_lo[STAGE_TILES + 1], dst_hi[STAGE_TILES + 1];   // the tile's first byte in the strip
@@ -208,8 +211,9 @@ struct KParams {
     const uint32_t* leaf_of;     // [n_sph+n_tri] primitive -> leaf node index (= DFS rank)
     const uint32_t* world_rank;  // [n_sph+n_tri] primitive -> position in RenderInfo.world, or nullptr (= primitive order): the
                                  //   tie order of plain linear-scan semantics (RT_FLAG_NO_BVH_CULL)
-    unsigned long long* strip_cost;  // optional [n_strips]: ray segments per strip of the batch (what the frame context balances devices by);
-                                 //   booked by tile: segments the wave traced between two tile fetches go to the tile it left
+    unsigned long long* strip_cost;  // optional [COST_COPIES][MAX_BATCH]: ray segments per strip of the batch (what the frame context balances its
+                                 //   devices by), in COST_COPIES partial sums (workgroup % COST_COPIES) so that the waves' atomics do not all
+                                 //   meet on one address per strip
     unsigned long long* counters;// [0] segments [1] candidates [2] fallbacks
     unsigned long long* queue;   // tile queue head of this launch (zeroed on the stream before it)
     StripDesc strips[MAX_BATCH];
@@ -654,9 +658,8 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
             wave_q[threadIdx.x >> 6].stack[threadIdx.x & 63u] = (uint8_t)(p.n_slots - 1u - min(threadIdx.x & 63u, p.n_slots - 1u));
         }
         if ((threadIdx.x & 63u) == 0u) {
-            wave_q[threadIdx.x >> 6].cost_last = 0ull;
-            wave_q[threadIdx.x >> 6].cost_acc = 0ull;
-            wave_q[threadIdx.x >> 6].cost_strip = 0xffffffffu;
+            wave_q[threadIdx.x >> 6].cost_acc[0] = wave_q[threadIdx.x >> 6].cost_acc[1] = 0u;
+            wave_q[threadIdx.x >> 6].cost_strip[0] = wave_q[threadIdx.x >> 6].cost_strip[1] = 0xffffffffu;
         }
         (void)z;
         if (CAN_STAGE && (threadIdx.x & 63u) <= STAGE_TILES) wave_st[threadIdx.x >> 6].left[threadIdx.x & 63u] = -1;
@@ -751,7 +754,6 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
     // ---- per-lane state
     bool have_unit = false, need_ray = false;
     uint32_t useq = 0;                        // the lane's unit: slot << 24 | unit within the slot
-    uint32_t px = 0, pyg = 0;                 // its pixel: column, GLOBAL row — live from acquisition to the camera ray only
     Rng rng = {0, 0, 0, 0};
     uint32_t depth_left = 0, k = 0;
     V3 o = mk(0, 0, 0), d = mk(0, 0, 0);
@@ -826,34 +828,17 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
     // q / spp for q < 65 * spp (a unit's place in its tile -> its pixel): a multiply-high (spp 1: the unit itself)
     auto div_spp = [&](uint32_t q) -> uint32_t { return p.spp_magic ? __umulhi(q, p.spp_magic) : q; };
 
-    // per-strip cost: the segments this wave traced since its last tile fetch go to the strip it was issuing from; the sum for a
-    // strip travels to the launch's array when the wave moves to another strip (and at its end): a handful of atomics per wave
-    auto book_cost = [&](uint32_t next_strip) {
-        const unsigned long long tot = wave_sum((unsigned long long)n_seg);
-        if (lane == 0) {
-            const unsigned long long last = wq.cost_last;
-            unsigned long long acc = wq.cost_acc + (tot >= last ? tot - last : tot);     // (tot < last: the counters were drained in between)
-            wq.cost_last = tot;
-            const uint32_t cs = wq.cost_strip;
-            if (cs != next_strip) {
-                if (acc && cs != 0xffffffffu) atomicAdd(&p.strip_cost[cs], acc);
-                acc = 0ull;
-                wq.cost_strip = next_strip;
-            }
-            wq.cost_acc = acc;
-        }
-    };
-
     TDECL;
     for (;;) {
         WCOUNT(0);
         TSTAMP(5);
+        uint32_t px = 0, pyg = 0;                 // a new unit's pixel: column, GLOBAL row — from the acquisition to the camera ray of this round
         // (the cursors are wave-uniform by construction; every assignment says so — uni() — so that they live in scalar registers
         // across the loop: left to the compiler they travelled through vector registers, a dozen moves per round)
         // ================= commit: complete slots -> pixels (main.rs:73-81)
         if (sp != p.n_slots) {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");          // the lanes' deposits of the last round
-            const bool slot_done = (uint32_t)lane < SLOTS_MAX && wq.cnt[lane & (int)(SLOTS_MAX - 1u)] == 0u;
+            const bool slot_done = (uint32_t)lane < SLOTS_MAX && (wq.cnt[lane & (int)(SLOTS_MAX - 1u)] & (SLOT_FREE | ((1u << SLOT_UNIT_BITS) - 1u))) == 0u;
             const uint32_t complete = (uint32_t)__ballot(slot_done);         // (an open slot's counter still holds its unissued units)
             const uint32_t n_complete = (uint32_t)__builtin_popcount(complete);
             // Worth the instructions?  A commit runs at one lane per pixel, so it waits until commit_slots are complete — unless
@@ -870,7 +855,7 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
                     const uint32_t slot = p.grp == 1u ? L : __umulhi(L, p.grp_magic), g = L - slot * p.grp;      // (grp > 1: below 8 spp only)
                     const bool mine = slot < p.n_slots && ((complete >> (slot & 31u)) & 1u) != 0u;
                     if (__ballot(mine) == 0ull) continue;
-                    uint32_t stg = STAGE_TILES;
+                    uint32_t stg = STAGE_TILES, cstrip = 0;
                     bool fin = false;
                     uint32_t pin = 0;
                     if (mine) {
@@ -882,6 +867,7 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
                         const uint32_t hmeta = __hip_atomic_load(reinterpret_cast<const uint32_t*>(sb) + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         const float* r = sb + 3u + g * p.spp * 3u;
                         float sum_r = 0.f, sum_g = 0.f, sum_b = 0.f;
+                        cstrip = hmeta & 0xffu;
                         {
                             // pix_color += (main.rs:75), s = 0 .. spp - 1; the loads of four samples in flight together
                             uint32_t i = 0;
@@ -950,6 +936,14 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
                             }
                             (void)pin;
                         }
+                    }
+                    if (p.strip_cost && mine && g == 0u) {
+                        // the slot's ray segments -> per-strip cost: into the wave's running sum for its strip (LDS: the strip the wave
+                        // issues from, or the one before), else — a straggler from further back — straight to the launch's array
+                        const uint32_t sg = wq.cnt[slot & (SLOTS_MAX - 1u)] >> SLOT_UNIT_BITS;
+                        if (cstrip == wq.cost_strip[0]) (void)__hip_atomic_fetch_add(&wq.cost_acc[0], sg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        else if (cstrip == wq.cost_strip[1]) (void)__hip_atomic_fetch_add(&wq.cost_acc[1], sg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        else if (sg) atomicAdd(&p.strip_cost[(blockIdx.x % COST_COPIES) * MAX_BATCH + cstrip], (unsigned long long)sg);
                     }
                     if (CAN_STAGE && __ballot(fin)) {
                         // staged tiles that are complete now: LDS -> three whole lines of the strip
@@ -1050,7 +1044,14 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
                     // decode the tile once, wave-uniformly: strip, tile origin, global row and seed
                     uint32_t tstrip;
                     decode_tile(t, tstrip, tile_x0, tile_row);
-                    if (p.strip_cost) book_cost(tstrip);
+                    if (p.strip_cost && lane == 0 && (wq.cost_strip[0] != tstrip || wq.cost_acc[0] >= 0x80000000u)) {
+                        // per-strip cost: the wave issues from another strip now; the sum of the strip before the last goes to the array
+                        if (wq.cost_acc[1]) atomicAdd(&p.strip_cost[(blockIdx.x % COST_COPIES) * MAX_BATCH + wq.cost_strip[1]], (unsigned long long)wq.cost_acc[1]);
+                        wq.cost_acc[1] = wq.cost_acc[0];
+                        wq.cost_strip[1] = wq.cost_strip[0];
+                        wq.cost_acc[0] = 0u;
+                        wq.cost_strip[0] = tstrip;
+                    }
                     tile_x0 = uni(tile_x0 + sub);
                     tile_row = uni(tile_row);
                     if (tile_x0 >= p.W) continue;                 // (a quarter beyond the right edge of a ragged tile: nothing in it)
@@ -2022,7 +2023,10 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
                     r[0] = term_r;
                     r[1] = term_g;
                     r[2] = term_b;
-                    (void)__hip_atomic_fetch_add(&wq.cnt[slot], 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    // one unit less to wait for, and the segments it traced (k hits on the path stack; the last segment ended in the sky
+                    // or on a light unless the depth ran out on a hit)
+                    const uint32_t usegs = k + ((hit && !(em > 0.0f)) ? 0u : 1u);
+                    (void)__hip_atomic_fetch_add(&wq.cnt[slot], (usegs << SLOT_UNIT_BITS) - 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                     have_unit = false;
                 }
             }
@@ -2030,7 +2034,8 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
         TSTAMP(4);
     }
 
-    if (p.strip_cost) book_cost(0xffffffffu);
+    if (p.strip_cost && lane < 2 && wq.cost_acc[lane])             // what the wave's running sums still hold
+        atomicAdd(&p.strip_cost[(blockIdx.x % COST_COPIES) * MAX_BATCH + wq.cost_strip[lane]], (unsigned long long)wq.cost_acc[lane]);
     drain_counters();
     TFLUSH;
 #undef wq
