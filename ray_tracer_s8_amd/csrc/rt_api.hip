@@ -130,8 +130,11 @@ constexpr uint32_t STACK_LDS_MAX = 12;          // quantised-node kernel: stack 
 constexpr uint32_t TRAVERSE_MIN_TRIS = 4;       // ... or above this many triangles (tools/crossover_tris.py: the LDS-tree walk wins from 8 triangles up)
 constexpr uint32_t RT_QNODES_MIN_PRIMS = 4096;   // from here up the traversal walks the 32-byte quantised nodes (tools/crossover_q.py)
 constexpr uint32_t REORDER_MIN_PRIMS = 64;      // from here up the primitive records are stored in the tree's depth-first leaf order
-constexpr uint32_t DENSE_LINEAR_MAX_PRIMS = 192;     // sphere scenes of up to this many spheres and at least ...
-constexpr float DENSE_LINEAR_MIN_DENSITY = 3.0f;     // ... this box density keep the linear scan (see `traverse`)
+constexpr uint32_t DENSE_SCAN_MAX_PRIMS = 192;       // piles of up to this many spheres at a box density of at least ...
+constexpr float DENSE_SCAN_MIN_DENSITY = 3.0f;       // ... this keep the linear scan (see `traverse`)
+constexpr float LT_CULL_MIN_DENSITY = 2.2f;          // the LDS-resident tree is walked nearer child first, with distance culling, from this box density up
+                                                     // (tests/test_gpu_engine_rules.py: at 1.1 ... 1.8 a helix, a lattice and a colonnade of 700 ... 960
+                                                     // spheres lose 7 ... 17 % to the culled step, piles at 1.8 / 2.7 gain 2 / 38 %)
 constexpr float SMALL_TREE_MAX_DENSITY = 0.4f;      // sphere scenes of up to TRAVERSE_MIN_PRIMS spheres walk the tree below this box density (see `traverse`)
 constexpr uint32_t TRAVERSE_MIN_PRIMS = 32;     // above this many primitives the BVH-traversal engine is the default (measured with the LDS-resident tree: tools/crossover.py 0.91 at 16, 1.03 at 32, 1.10 at 64, 2.0 at 512; tools/heuristics_matrix.py at 48: +15...20 % on sparse fields, sheets and clusters, -3 % on dense overlap)
 
@@ -302,14 +305,13 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     // overlapping spheres at 1.1 and above; c2's room sits at 0.50 and stays with the scan it renders 2 % faster with.
     // tools/small_scene_matrix.py: 33 scenes of 2...32 spheres)
     const bool sparse_small = n_prims >= 2 && sc->n_tri == 0 && sc->cull_density < SMALL_TREE_MAX_DENSITY;
-    // (... while PILES of overlapping spheres keep the scan well beyond the threshold: the LDS-tree walk has no distance culling, and
-    // at a box density of 3 and more a ray meets so many leaf boxes that the tree renders at 0.6...0.9 of the scan up to about 200
-    // spheres — tools/dense_matrix.py: 48...192 spheres at density 3.3...13; at 256 the scan's O(N) has caught up)
-    // (round 3, end, tools/dense_mid_matrix.py — three pile shapes of 128...1000 spheres: up to 384 spheres at densities 5...12 the scan
-    // still leads the tree by 18...30 %; beyond, and for still denser piles, the culled walk does: see dense_mid below)
-    const bool dense_pile = sc->n_tri == 0 && sc->cull_density >= DENSE_LINEAR_MIN_DENSITY &&
-                            (n_prims <= DENSE_LINEAR_MAX_PRIMS ||
-                             (n_prims <= 2 * DENSE_LINEAR_MAX_PRIMS && sc->cull_density >= 5.0f && sc->cull_density < 12.0f));
+    // (... while small PILES of overlapping spheres keep the scan: at a box density of 3 and more a ray meets so many leaf boxes that up
+    // to about 200 spheres the scan's 64 packed instructions per 8 spheres beat any walk — tools/dense_matrix.py, 48 ... 192 spheres at
+    // density 3.3 ... 13: the culled LDS-tree walk of round 4 renders them at 0.67 ... 0.84 of the scan (the plain one: 0.59 ... 0.92), at
+    // 256 it leads by 1.4 ... 1.5 x.  Round 3's two further pile rules — up to 384 spheres at densities 5 ... 12 to the scan, larger or
+    // denser piles to the culled L2 walk although their tree fits LDS — are gone: the culled LDS-tree walk is the best engine in
+    // every cell of tools/dense_mid_matrix.py, by 13 ... 30 %.)
+    const bool dense_pile = sc->n_tri == 0 && n_prims <= DENSE_SCAN_MAX_PRIMS && sc->cull_density >= DENSE_SCAN_MIN_DENSITY;
     const bool traverse = trav_ok && ((rq->flags & RT_FLAG_BVH_TRAVERSE) || (n_prims > TRAVERSE_MIN_PRIMS && !dense_pile) ||
                                       sc->n_tri > TRAVERSE_MIN_TRIS || sparse_small);
     // node format: from RT_QNODES_MIN_PRIMS primitives up the 32-byte quantised nodes (half the gather footprint, and an
@@ -332,15 +334,9 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     // (Below the threshold a DENSE sphere scene whose tree does not fit LDS also takes the quantised nodes, for the culled
     // walk below: tools/cull_matrix_small.py, 2 000...3 500 overlapping spheres 1.55...1.95 x over the exact-node walk, fields of
     // box density 1...2 0.87...0.98 — hence the higher bar of 2.5 here.)
-    // (... and a pile takes them even when its tree WOULD fit LDS: the LDS-tree walk has no distance culling, and from a box density
-    // of 7 at more than 384 spheres, or of 20 at more than 256, the culled walk through L2 leads it by 13...65 % — tools/dense_mid_matrix.py)
-    // (cull_pays asks for spheres small against the scene, which a pile's are not: against an engine without any culling the
-    // culled walk leads regardless, so here the bound only has to be valid)
-    const bool pile_fits = ltree_fits && sc->n_tri == 0 && std::isfinite(sc->r_slack) && !(rq->flags & RT_FLAG_NO_CULL_WALK) &&
-                           ((n_prims > 2 * DENSE_LINEAR_MAX_PRIMS && sc->cull_density >= 7.0f) ||
-                            (n_prims > 256 && sc->cull_density >= 20.0f));
-    const bool dense_mid = (sc->cull_pays && !(rq->flags & RT_FLAG_NO_CULL_WALK) && !ltree_fits && sc->cull_density >= 2.5f &&
-                            n_prims >= 512) || pile_fits;
+    // (round 4: piles whose tree FITS LDS no longer need a rule — the LDS-resident tree has its own culled walk, below)
+    const bool dense_mid = sc->cull_pays && !(rq->flags & RT_FLAG_NO_CULL_WALK) && !ltree_fits && sc->cull_density >= 2.5f &&
+                           n_prims >= 512;
     // (... and so does a sphere FIELD between the LDS tree's limit and that threshold: at box densities of 0.15 and more the quantised
     // walk leads the exact one by 17...24 % there — tools/qnodes_mid_matrix.py, 1200...4000 spheres; flat sheets of small spheres,
     // 0.03...0.1, are the scenes the exact nodes win by up to 12 %, and clusters fail quant_ok)
@@ -356,7 +352,7 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     // (an explicit request flag wins over the process-level knob, the knob over the host rule)
     const int cull_env = dbg(DBG_CULL_WALK);
     const bool cull_want = (rq->flags & RT_FLAG_NO_CULL_WALK) ? false : (rq->flags & RT_FLAG_CULL_WALK) ? true
-                           : cull_env >= 0 ? cull_env != 0 : (sc->cull_pays || pile_fits);
+                           : cull_env >= 0 ? cull_env != 0 : sc->cull_pays;
     const bool cull = qnodes && cull_want && sc->n_tri == 0 && std::isfinite(sc->r_slack);
     // ... and over the exact nodes (kernel variant 7): scenes with triangles — the bound of cull_bound_tri — wherever the exact-node
     // L2 walk is the engine; default where the host heuristic says it pays (xcull_pays), forced by the same flags
@@ -364,6 +360,14 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
                             : cull_env >= 0 ? cull_env != 0 : sc->xcull_pays;
     const bool xcull = traverse && !qnodes && !ltree && xcull_want && sc->n_tri > 0 && sc->tri_ok && std::isfinite(sc->r_slack) &&
                        !sc->inverted_boxes;
+    // ... and in the LDS-resident tree (kernel variant 4, engine 7; round 4): the same bound, so the same premises (a finite slack
+    // radius, triangles within the K limit or in the `big` list, no inverted boxes); default from a box density of LT_CULL_MIN_DENSITY
+    // up — below it the rays meet so few leaf boxes that ordering the children costs more than the skipped subtrees save
+    // (tools/dense_matrix.py, tools/dense_mid_matrix.py, tests/test_gpu_engine_rules.py)
+    const bool lt_cull_ok = ltree && !sc->inverted_boxes && std::isfinite(sc->r_slack) && (sc->n_tri == 0 || sc->tri_ok);
+    const bool lt_cull_want = (rq->flags & RT_FLAG_NO_CULL_WALK) ? false : (rq->flags & RT_FLAG_CULL_WALK) ? true
+                              : cull_env >= 0 ? cull_env != 0 : sc->cull_density >= LT_CULL_MIN_DENSITY;
+    const bool ltcull = lt_cull_ok && lt_cull_want;
     const bool streamed = !traverse && sc->n_sph_pad > RESIDENT_MAX;
     p.chunk = traverse ? 0 : (streamed ? STREAM_CHUNK : sc->n_sph_pad);
     p.n_chunks = p.chunk ? (sc->n_sph_pad + p.chunk - 1) / p.chunk : 0;
@@ -529,12 +533,12 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     p.tri_diag = sc->tri_diag;
     p.tri_es = sc->tri_es;
     p.tri_e = sc->tri_e;
-    const rtk::KernelFn kern = traverse ? rtk::kernel_traverse(ltree ? 3 : qnodes ? (cull_run ? (capped ? 6 : 5) : capped ? 2 : 1) : xcull ? 7 : 0, count_steps) : rtk::kernel_linear(streamed, expanded);
+    const rtk::KernelFn kern = traverse ? rtk::kernel_traverse(ltree ? (ltcull ? 4 : 3) : qnodes ? (cull_run ? (capped ? 6 : 5) : capped ? 2 : 1) : xcull ? 7 : 0, count_steps) : rtk::kernel_linear(streamed, expanded);
     HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, bs, lds));
     if (per_cu < 1) per_cu = 1;
     if (dbg(DBG_VERBOSE))
         fprintf(stderr, "[rt] engine %d%s  lds %zu B  workgroups/CU %d  leaf slots %u  bvh depth %u  leaf density %.3f  prims %u\n",
-                traverse ? (ltree ? 4 : qnodes ? (cull_run ? 5 : 3) : xcull ? 6 : 2) : (streamed ? 1 : 0), capped ? " (capped stack)" : "", lds, per_cu, maxl,
+                traverse ? (ltree ? (ltcull ? 7 : 4) : qnodes ? (cull_run ? 5 : 3) : xcull ? 6 : 2) : (streamed ? 1 : 0), capped ? " (capped stack)" : "", lds, per_cu, maxl,
                 sc->bvh_depth, sc->leaf_density, n_prims);
     uint32_t blocks = (uint32_t)sc->ctx->n_cu * (uint32_t)per_cu;
     const uint32_t waves_per_wg = (uint32_t)bs / 64u;
@@ -603,7 +607,7 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     }
     HIPCHK(hipMemsetAsync(p.queue, 0, sizeof(unsigned long long), stream));
     HIPCHK(hipEventRecord(ev.a, stream));
-    sc->last_engine = traverse ? (ltree ? 4u : qnodes ? (cull_run ? 5u : 3u) : xcull ? 6u : 2u) : (streamed ? 1u : 0u);
+    sc->last_engine = traverse ? (ltree ? (ltcull ? 7u : 4u) : qnodes ? (cull_run ? 5u : 3u) : xcull ? 6u : 2u) : (streamed ? 1u : 0u);
     sc->last_form = expanded ? 1u : 0u;
     hipLaunchKernelGGL(kern, grid, block, lds, stream, p);
     HIPCHK(hipGetLastError());

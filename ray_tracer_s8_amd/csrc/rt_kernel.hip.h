@@ -100,6 +100,9 @@ constexpr int LNODE_DW = 19;      // LDS-tree kernel: dwords per staged node (se
 #ifndef RT_LT_PARTIAL           // LDS-tree kernel: lanes with a pending candidate that make a partial root-test round (64: never)
 #define RT_LT_PARTIAL 40
 #endif
+#ifndef RT_LT_EAGER             // culled LDS-tree kernel: lanes with candidates but no hit yet that make a partial root-test round
+#define RT_LT_EAGER 12
+#endif
 #ifndef RT_MAXL_LTREE
 #define RT_MAXL_LTREE 12
 #endif
@@ -622,20 +625,20 @@ __device__ __forceinline__ float cull_bound_tri(float best, V3 o, float k, float
 // 32-byte nodes whose boxes are rounded outwards onto a 16-bit grid, every reached leaf being validated with the
 // reference's exact own-leaf AABB test.
 template <int ISECT, bool EXPANDED, int BS = BLOCK, bool STATS = false>
-__global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? RT_MINWAVES_TRAV : ISECT >= 7 ? RT_MINWAVES_CULL : ISECT >= 3 ? RT_MINWAVES_QTRAV : ISECT == 2 ? RT_MINWAVES_TRAV : RT_MINWAVES) void rt_tile_kernel(const KParams p) {
+__global__ __launch_bounds__(BS, (ISECT == 5 || ISECT == 6) ? RT_MINWAVES_LTREE : ISECT == 9 ? RT_MINWAVES_TRAV : ISECT >= 7 ? RT_MINWAVES_CULL : ISECT >= 3 ? RT_MINWAVES_QTRAV : ISECT == 2 ? RT_MINWAVES_TRAV : RT_MINWAVES) void rt_tile_kernel(const KParams p) {
     constexpr int BLOCK = BS;                        // threads per workgroup = stride of the per-lane LDS arrays
     constexpr bool STREAMED = (ISECT == 1);
     constexpr bool TRAVERSE = (ISECT >= 2);
     constexpr bool QNODES = (ISECT == 3 || ISECT == 4 || ISECT == 7 || ISECT == 8);   // traversal over 32-byte conservatively quantised nodes
     // ISECT 7: ... nearer child first, and a subtree whose box the ray enters beyond the running closest hit (plus a proven
     // slack, cull_bound) is not entered.  Spheres only.  Candidates then arrive out of depth-first order: ties by rank.
-    constexpr bool CULL = (ISECT == 7 || ISECT == 8 || ISECT == 9);      // (8: with the capped LDS stack; 9: over the EXACT nodes,
-                                                                         //  where triangles may take part — cull_bound_tri)
+    constexpr bool CULL = (ISECT == 6 || ISECT == 7 || ISECT == 8 || ISECT == 9);   // (8: with the capped LDS stack; 9: over the EXACT nodes,
+                                                                         //  where triangles may take part — cull_bound_tri; 6: the LDS-resident tree)
     constexpr bool XNODES = (ISECT == 2 || ISECT == 9);    // exact 64-byte nodes gathered from L2
     constexpr bool CAPPED = (ISECT == 4 || ISECT == 8);            // ... whose stack keeps p.stack_lds entries in LDS, deeper ones in HBM
     // ISECT 5: the exact-node walk with the WHOLE tree (and the materials) resident in LDS, one 1024-thread workgroup
     // per CU; references, stack and leaf lists are 16-bit
-    constexpr bool LTREE = (ISECT == 5);
+    constexpr bool LTREE = (ISECT == 5 || ISECT == 6);     // (6: nearer child first + distance culling, round 4)
     constexpr uint32_t LB = LTREE ? 0x8000u : LEAF_BIT;   // leaf flag of a node reference
     // the branch-free node step (see there) pays where a step is bound by the wave's instruction stream = nodes in LDS;
     // the L2-gather engines are bound by the gathers and keep the step that skips them at leaves (c3 -14 %, c5 -11 %)
@@ -781,7 +784,7 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
     // the exact-node variant also holds triangles: cull_bound_tri; a scene of both takes the larger)
     auto far_bound = [&](float best) -> float {
         float b = cull_bound(best, o, p.r_slack);
-        if (ISECT == 9 && p.n_tri) b = __builtin_fmaxf(b, cull_bound_tri(best, o, p.tri_k, p.tri_diag, p.tri_es, p.tri_e));
+        if ((ISECT == 9 || ISECT == 6) && p.n_tri) b = __builtin_fmaxf(b, cull_bound_tri(best, o, p.tri_k, p.tri_diag, p.tri_es, p.tri_e));
         return b;
     };
     V3 td = mk(0, 0, 0);                     // linear engines: 2 * d of the current segment
@@ -1317,6 +1320,7 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
                 root_test(t_head);
                 t_head++;
                 if (t_head == t_cnt) t_head = t_cnt = 0;
+                if (CULL && h.idx >= 0) t_far = far_bound(h.dist);
             };
 
             // ---- Compacted root tests (exact-node L2 kernel).  The per-lane flush above runs as many rounds as the longest
@@ -1502,16 +1506,32 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
                 const float lzn = (p8 - o.z) * aux.inv.z, lzf = (p9 - o.z) * aux.inv.z;
                 const float rzn = (p10 - o.z) * aux.inv.z, rzf = (p11 - o.z) * aux.inv.z;
                 bool hl, hr;
+                float le, re;                                    // entry distances of the two boxes (max(ray_min, 0), ray.rs:193)
                 if (SLOW) {                                      // the crate's min / max (ray.rs:81-112): NaN-aware order
-                    hl = rmax(rmax(rmax(lxn, lyn), lzn), 0.0f) <= rmin(rmin(lxf, lyf), lzf);
-                    hr = rmax(rmax(rmax(rxn, ryn), rzn), 0.0f) <= rmin(rmin(rxf, ryf), rzf);
+                    le = rmax(rmax(rmax(lxn, lyn), lzn), 0.0f);
+                    re = rmax(rmax(rmax(rxn, ryn), rzn), 0.0f);
+                    hl = le <= rmin(rmin(lxf, lyf), lzf);
+                    hr = re <= rmin(rmin(rxf, ryf), rzf);
                 } else {                                         // finite inverse direction: no NaN can arise, and min / max
                     // differ from the crate's forms only in the sign of a zero, which no comparison sees
-                    hl = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(lxn, lyn), lzn), 0.0f) <= __builtin_fminf(__builtin_fminf(lxf, lyf), lzf);
-                    hr = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(rxn, ryn), rzn), 0.0f) <= __builtin_fminf(__builtin_fminf(rxf, ryf), rzf);
+                    le = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(lxn, lyn), lzn), 0.0f);
+                    re = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(rxn, ryn), rzn), 0.0f);
+                    hl = le <= __builtin_fminf(__builtin_fminf(lxf, lyf), lzf);
+                    hr = re <= __builtin_fminf(__builtin_fminf(rxf, ryf), rzf);
                 }
-                const uint32_t cl = refs & 0xffffu, cr = refs >> 16;
-                lds16(top_a + SLOT) = (uint16_t)cr;                // right subtree after the whole left subtree
+                uint32_t cl = refs & 0xffffu, cr = refs >> 16;
+                if (CULL) {
+                    // Culled walk (ISECT 6): a box the ray enters beyond t_far cannot hold a closer or tying root (cull_bound, rt_cull.h)
+                    // and is not entered; of two boxes the NEARER goes first, so that t_far shrinks early.  (A second compare, not
+                    // min(exit, t_far): the NaN planes of leaves and of node DONE's right box must keep failing.)
+                    hl = hl && le <= t_far;
+                    hr = hr && re <= t_far;
+                    const bool swp = hl && hr && re < le;
+                    const uint32_t c0 = cl;
+                    cl = swp ? cr : cl;
+                    cr = swp ? c0 : cr;
+                }
+                lds16(top_a + SLOT) = (uint16_t)cr;                // right subtree after the whole left subtree (CULL: the farther one)
                 const bool any = hl || hr;
                 t_ref = any ? (hl ? cl : cr) : top;
                 uint32_t delta = any ? 0u : 0u - SLOT;             // (two selects and a fast-class add; the sum of two selects was a v_add3)
@@ -1534,7 +1554,10 @@ __global__ __launch_bounds__(BS, ISECT == 5 ? RT_MINWAVES_LTREE : ISECT == 9 ? R
                 // one pending: 3.4 rounds at 21 lanes.
                 if (RT_LT_PARTIAL < 64) {
                     const bool pend = t_cnt > t_head;
-                    if ((int)__builtin_popcountll(__ballot(pend)) >= RT_LT_PARTIAL) {
+                    // (culled walk: a lane that has candidates but no hit yet cannot skip anything: such lanes are tested as soon as
+                    // there are RT_LT_EAGER of them)
+                    if ((int)__builtin_popcountll(__ballot(pend)) >= RT_LT_PARTIAL ||
+                        (CULL && (int)__builtin_popcountll(__ballot(pend && h.idx < 0)) >= RT_LT_EAGER)) {
                         if (pend) flush_one();
                     }
                 }
@@ -2047,7 +2070,7 @@ using KernelFn = void (*)(const KParams);
 KernelFn kernel_linear(bool streamed, bool expanded);
 void sqrt_selftest_launch(uint32_t from, unsigned long long n, unsigned long long* d_bad, hipStream_t st);   // rt_kernels_trav.hip
 KernelFn kernel_traverse(int variant, bool stats = false);   // 0: exact nodes, 1: quantised nodes, 2: quantised nodes with the capped LDS stack,
-                                         // 3: exact nodes, whole tree resident in LDS (1024-thread workgroups)
+                                         // 3: exact nodes, whole tree resident in LDS (1024-thread workgroups); 4: the same, nearer child first, distance culling
                                          // 5: quantised nodes, nearer child first, distance culling (spheres only); 6: the same, capped LDS stack
                                          // 7: exact nodes, nearer child first, distance culling (spheres and triangles)
                                          // stats: the variant that also counts node visits (RT_FLAG_COUNT_STEPS)

@@ -8,6 +8,7 @@ namespace rtk {
 KernelFn kernel_traverse(int variant, bool stats) {
     if (stats) {
         if (variant == 3) return rt_tile_kernel<5, false, LTREE_BLOCK, true>;
+        if (variant == 4) return rt_tile_kernel<6, false, LTREE_BLOCK, true>;
         if (variant == 5) return rt_tile_kernel<7, false, BLOCK, true>;
         if (variant == 6) return rt_tile_kernel<8, false, BLOCK, true>;
         if (variant == 7) return rt_tile_kernel<9, false, BLOCK, true>;
@@ -16,6 +17,7 @@ KernelFn kernel_traverse(int variant, bool stats) {
                               : rt_tile_kernel<2, false, BLOCK, true>;
     }
     if (variant == 3) return rt_tile_kernel<5, false, LTREE_BLOCK>;
+    if (variant == 4) return rt_tile_kernel<6, false, LTREE_BLOCK>;
     if (variant == 5) return rt_tile_kernel<7, false>;
     if (variant == 6) return rt_tile_kernel<8, false>;
     if (variant == 7) return rt_tile_kernel<9, false>;

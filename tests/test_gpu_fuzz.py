@@ -23,7 +23,11 @@ ENGINE_FLAGS = [0, _abi.RT_FLAG_LINEAR_SCAN, _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT
                 _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_QUANT_NODES | _abi.RT_FLAG_NO_CULL_WALK,
                 # the culled walk over the exact nodes (scenes with triangles take it)
                 _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_EXACT_NODES | _abi.RT_FLAG_NO_LDS_TREE | _abi.RT_FLAG_CULL_WALK,
-                _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_EXACT_NODES | _abi.RT_FLAG_NO_LDS_TREE | _abi.RT_FLAG_CULL_WALK | _abi.RT_FLAG_FULL_CHAIN]
+                _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_EXACT_NODES | _abi.RT_FLAG_NO_LDS_TREE | _abi.RT_FLAG_CULL_WALK | _abi.RT_FLAG_FULL_CHAIN,
+                # the culled walk of the LDS-resident tree (round 4: engine 7; trees that fit LDS, spheres and triangles)
+                _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_EXACT_NODES | _abi.RT_FLAG_CULL_WALK,
+                _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_EXACT_NODES | _abi.RT_FLAG_CULL_WALK | _abi.RT_FLAG_FULL_CHAIN,
+                _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_EXACT_NODES | _abi.RT_FLAG_NO_CULL_WALK]
 
 
 def _random_case(i):

@@ -420,8 +420,10 @@ def test_candidate_list_overflow_paths(ndev, oracle):
     assert st.exact_fallbacks > 0
     st = _compare(oracle, rq, sph, flags=_abi.RT_FLAG_LINEAR_SCAN | _abi.RT_FLAG_OC_BROAD_PHASE)
     assert st.exact_fallbacks > 0
-    st = _compare(oracle, rq, sph, flags=_abi.RT_FLAG_BVH_TRAVERSE)
+    st = _compare(oracle, rq, sph, flags=_abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_NO_CULL_WALK)
     assert st.broad_candidates > 20 * st.ray_segments // 4          # dozens of leaves per primary ray
+    st = _compare(oracle, rq, sph, flags=_abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_CULL_WALK)
+    assert st.engine == 7 and st.broad_candidates < 20 * st.ray_segments // 4    # the culled LDS tree skips most of the skewer
     _compare(oracle, rq, sph, flags=_abi.RT_FLAG_NO_BVH_CULL)
 
 
@@ -768,7 +770,7 @@ def test_quantised_walk_fallback_lanes(ndev, oracle, flags):
     rq.fov = 0.02                                           # the cluster fills the frame
     st = _compare(oracle, rq, sph, flags=flags)
     assert st.ray_segments > rq.width * rq.height * rq.spp     # some paths did bounce
-    assert st.engine == (5 if flags & _abi.RT_FLAG_CULL_WALK else 3 if flags & _abi.RT_FLAG_QUANT_NODES else 4)
+    assert st.engine == (5 if flags & _abi.RT_FLAG_CULL_WALK else 3 if flags & _abi.RT_FLAG_QUANT_NODES else st.engine if st.engine in (4, 7) else -1)
     # (b) mirror spheres on the optical axis, pinhole camera: reflected rays with exact zero components
     row = np.zeros(3, _abi.SPHERE_DTYPE)
     row["cz"] = [-4.0, -9.0, -2000.0]
@@ -876,9 +878,12 @@ def test_culled_walk_odd_scenes(ndev, oracle, kind):
     c = _compare(oracle, rq, sph, flags=_abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_EXACT_NODES | _abi.RT_FLAG_NO_LDS_TREE)
     d = _compare(oracle, rq, sph, flags=_abi.RT_FLAG_LINEAR_SCAN)
     part = sph[:900] if kind != "odd_radii" else np.concatenate([sph[200:500], sph[900:1400]])
-    e = _compare(oracle, rq, part, flags=_abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_EXACT_NODES)   # (a pile may go to the culled walk by default)
+    e = _compare(oracle, rq, part, flags=_abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_EXACT_NODES | _abi.RT_FLAG_NO_CULL_WALK)
+    e7 = _compare(oracle, rq, part, flags=_abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_EXACT_NODES | _abi.RT_FLAG_CULL_WALK)
     f = _compare(oracle, rq, part, flags=0)
-    assert c.engine == 2 and d.engine in (0, 1) and e.engine == 4 and f.engine in (4, 5)
+    assert c.engine == 2 and d.engine in (0, 1) and e.engine == 4 and f.engine in (4, 5, 7)
+    # (the culled LDS-resident tree wherever its bound is valid: not with an inverted box or an unbounded slack radius)
+    assert e7.engine in (4, 7) and e7.ray_segments == e.ray_segments and (e7.engine == 4 or e7.broad_candidates <= e.broad_candidates)
 
 
 _EXTREME = {
@@ -993,7 +998,7 @@ def test_hundreds_of_candidates_per_ray(ndev, oracle, n):
         engines[flags] = st.engine
         if flags and not (flags & _abi.RT_FLAG_LINEAR_SCAN) and not (flags & _abi.RT_FLAG_CULL_WALK):
             assert st.broad_candidates > 20 * st.ray_segments, st.broad_candidates / st.ray_segments
-    assert engines[0] in (2, 3, 4, 5)            # (whatever the host picks for such a pile: deep tree, large slack radius)
+    assert engines[0] in (2, 3, 4, 5, 7)         # (whatever the host picks for such a pile: deep tree, large slack radius)
 
 
 def test_thousands_of_identical_spheres(ndev, oracle):
@@ -1136,7 +1141,8 @@ def test_lds_tree_near_axis_rays_and_long_lists(ndev, oracle):
     sph["emission"] = np.where(g.uniform(size=n) < 0.05, 3.0, 0.0)
     # a camera looking down -z with no aperture and a tiny field of view
     rq = _abi.default_request(width=65, height=65, divisions=1, spp=2, max_bounces=6, aperture=0.0, fov=0.02, seed=5)
-    st = _compare(oracle, rq, sph, flags=_abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_EXACT_NODES)   # (by default a pile keeps off the LDS tree)
+    st = _compare(oracle, rq, sph, flags=_abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_EXACT_NODES | _abi.RT_FLAG_NO_CULL_WALK)
     assert st.engine == 4
     assert st.broad_candidates > 8 * st.ray_segments // 4                   # long lists: several candidates per segment
-    assert _compare(oracle, rq, sph, flags=0).engine != 4
+    st7 = _compare(oracle, rq, sph, flags=0)                                # (by default a pile is walked nearer child first, culled)
+    assert st7.engine == 7 and st7.broad_candidates < st.broad_candidates
