@@ -1225,6 +1225,11 @@ __global__ __launch_bounds__(BS, (ISECT == 5 || ISECT == 6) ? RT_MINWAVES_LTREE 
                        __builtin_fabsf(og.x) < 0x1p18f && __builtin_fabsf(og.y) < 0x1p18f && __builtin_fabsf(og.z) < 0x1p18f;
             }
             if (LTREE) {
+                // (the fast step's finished lanes idle on node DONE, whose all-of-space box is entered by every ray with a FINITE origin
+                // and a finite non-zero inverse direction; any other lane walks the SLOW step, which clamps its stack pointer — round-3
+                // advisor: an origin at infinity, (-inf - o) * inv = NaN, would otherwise pop below slot 0)
+                aux.finite = aux.finite && __builtin_fabsf(o.x) < __builtin_inff() && __builtin_fabsf(o.y) < __builtin_inff() &&
+                             __builtin_fabsf(o.z) < __builtin_inff();
                 sgx = aux.sx ? 1u : 0u;
                 sgy = aux.sy ? 1u : 0u;
                 sgz = aux.sz ? 1u : 0u;
@@ -1452,9 +1457,8 @@ __global__ __launch_bounds__(BS, (ISECT == 5 || ISECT == 6) ? RT_MINWAVES_LTREE 
             //     finished lane idles there until the block ends — no emptiness test, no per-lane exit, and (round 3) no clamp
             //     of the stack pointer: the lane neither pushes nor pops.  A lane whose inverse direction is not finite may
             //     miss even that box (-inf * -inf); it walks the SLOW variant, which keeps the clamp, and there DONE pops DONE;
-            //   * a lane at a leaf gathers node MISS (= n_internal + 1, NaN planes: no ray enters), so both slab results are
-            //     false and it pops.  MISS is the last node and every leaf reference (flag 0x8000) is larger than its offset,
-            //     so the node to gather is min(reference, MISS): one instruction;
+            //   * a lane at a leaf forms its node address like any other — base + 4 * reference — and lands in the NaN field behind the
+            //     tree (staging code above): NaN planes, both slab results false, it pops; no clamp of the reference (round 3);
             //   * the right child is stored to stack[t_sp], the next free slot, pushed or not (t_sp += both);
             //   * every reference is stored to list[t_cnt], the next free list slot, and only a leaf advances t_cnt;
             //   * the leaf list has room for a whole block of appends (checked between blocks): no fullness test.

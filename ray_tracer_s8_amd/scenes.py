@@ -209,11 +209,15 @@ def config(name: str) -> tuple[np.ndarray, TileRequest]:
         # (1920x1080, 20 strips); spheres = none, triangles = mesh_world()
         return np.zeros(0, SPHERE_DTYPE), default_request(width=1920, height=1080, divisions=20, spp=4, max_bounces=4,
                                                           seed=0x0B1E5)
+    if name == "mesh_ref":
+        # the same mesh at the reference's LITERAL settings: 1920x1080, 20 strips (controller main.rs:33-39), 100 samples per pixel,
+        # 10 bounces (slave main.rs:39, 51) — what a job of the shipped controller + slave actually renders
+        return np.zeros(0, SPHERE_DTYPE), default_request(seed=0x0B1E5)
     raise KeyError(name)
 
 
 def config_world(name: str):
-    """(spheres, triangles, request template): config() plus the triangle list of the mesh workload."""
+    """(spheres, triangles, request template): config() plus the triangle list of the mesh workloads."""
     sph, rq = config(name)
-    tri = mesh_world() if name == "mesh" else np.zeros(0, TRIANGLE_DTYPE)
+    tri = mesh_world() if name in ("mesh", "mesh_ref") else np.zeros(0, TRIANGLE_DTYPE)
     return sph, tri, rq

