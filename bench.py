@@ -460,10 +460,12 @@ def main():
                    if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR",
                                 "MASTER_PORT", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS")}
             fpath_all = {}
-            for name, extra in (("static", []), ("strip_queue", ["--frame-queue"])):
+            # (three assignments: the default — snake on frame 1, then longest-first by the measured per-strip costs —, the round 1-3
+            # split k mod n, and the strip queue; each child at most two minutes, well inside the barrier's collective timeout)
+            for name, extra in (("balanced", []), ("static_k_mod_n", ["--frame-static"]), ("strip_queue", ["--frame-queue"])):
                 try:
                     pr = subprocess.run([sys.executable, str(Path(__file__).resolve()), "--frame", "--workload", "c4", "--steps", "3",
-                                         "--frame-devices", devs] + extra, capture_output=True, text=True, timeout=300, env=env)
+                                         "--frame-devices", devs] + extra, capture_output=True, text=True, timeout=120, env=env)
                     last = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
                     fpath_all[name] = json.loads(last[-1])["frame_path"] if pr.returncode == 0 and last else \
                         {"error": f"rc {pr.returncode}: {pr.stderr[-400:]}"}
@@ -507,14 +509,15 @@ def main():
                 d = dict(d)
                 d["source"] = f"committed profile profiles/{name} (rocprofv3 --pmc pass of this command, not measured in this run)"
             return d
-        traffic_rec = committed("r03_hbm_traffic.json") or committed("r02_hbm_traffic.json")
-        issue = committed("r03_valu_issue.json") or committed("r02_valu_issue.json")
+        traffic_rec = committed("r04_hbm_traffic.json") or committed("r03_hbm_traffic.json")
+        issue = committed("r04_valu_issue.json") or committed("r03_valu_issue.json")
         eng_names = ["linear scan, scene resident in LDS", "linear scan, scene streamed through LDS",
                      "per-lane traversal of the reference BVH (exact nodes gathered from L2)",
                      "per-lane traversal of the reference BVH (quantised nodes, exact leaf validation)",
                      "per-lane traversal of the reference BVH (exact nodes resident in LDS)",
                      "per-lane traversal of the reference BVH (quantised nodes, nearer child first, distance culling, exact leaf validation)",
-                     "per-lane traversal of the reference BVH (exact nodes gathered from L2, nearer child first, distance culling)"]
+                     "per-lane traversal of the reference BVH (exact nodes gathered from L2, nearer child first, distance culling)",
+                     "per-lane traversal of the reference BVH (exact nodes resident in LDS, nearer child first, distance culling)"]
         line = {
             "metric": "Mrays/sec @ 4K/8spp 1024-sphere" if args.workload == "c3" else f"Mrays/sec @ {args.workload}",
             "value": segs / elapsed / 1e6,
@@ -550,6 +553,9 @@ def main():
                 "peak": peak_tflops,
                 "unit": "TFLOP/s",
                 "frac": achieved_tflops / peak_tflops,
+                # (rounds 1-2 divided the traversal engines' flops by the FMA peak, 157.3 T: the same achieved figure on that scale,
+                # so that lines of different rounds can be compared — round-3 advisor)
+                "frac_fma_peak": achieved_tflops / PEAK_FP32_VALU_TFLOPS,
                 "peak_note": "non-FMA FP32 vector peak (sub / mul / compare, 1 flop per lane per issue; SURVEY 8(d) parity mode)"
                              if st.engine >= 2 else "FP32 vector peak, FMA = 2 flop (the broad phase is packed fma)",
                 # SURVEY 8(d)'s own figure, as named there: ray_segments x 20 x N / t / 78.6e12.  For the traversal engines

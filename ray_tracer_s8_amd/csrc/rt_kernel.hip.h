@@ -589,6 +589,16 @@ __device__ __forceinline__ const T& at32(const T* __restrict__ base, uint32_t i)
     return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + i * (uint32_t)sizeof(T));
 }
 
+// A loop-invariant index used in a COLD place of the loop (the path stack: once per round): opaque to the compiler, so that the address
+// built from it is formed where it is used — two instructions a round — instead of living in a vector register across the walk
+// (the register-bound quantised kernels spilled exactly such addresses)
+// ON only in the kernels that are bound by their registers (the quantised walks, 96 VGPRs = five waves per SIMD: c5 +1.4 %; in the
+// others the two instructions cost 1 %).
+template <bool ON>
+__device__ __forceinline__ int cold(int v) {
+    if (ON) asm volatile("" : "+v"(v));
+    return v;
+}
 // a wave-uniform value read through a vector register (LDS): back into a scalar register
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
@@ -841,7 +851,7 @@ __global__ __launch_bounds__(BS, (ISECT == 5 || ISECT == 6) ? RT_MINWAVES_LTREE 
         // ================= commit: complete slots -> pixels (main.rs:73-81)
         if (sp != p.n_slots) {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");          // the lanes' deposits of the last round
-            const bool slot_done = (uint32_t)lane < SLOTS_MAX && (wq.cnt[lane & (int)(SLOTS_MAX - 1u)] & (SLOT_FREE | ((1u << SLOT_UNIT_BITS) - 1u))) == 0u;
+            const bool slot_done = (uint32_t)lane < SLOTS_MAX && (wq.cnt[cold<QNODES>(lane) & (int)(SLOTS_MAX - 1u)] & (SLOT_FREE | ((1u << SLOT_UNIT_BITS) - 1u))) == 0u;
             const uint32_t complete = (uint32_t)__ballot(slot_done);         // (an open slot's counter still holds its unissued units)
             const uint32_t n_complete = (uint32_t)__builtin_popcount(complete);
             // Worth the instructions?  A commit runs at one lane per pixel, so it waits until commit_slots are complete — unless
@@ -971,7 +981,7 @@ __global__ __launch_bounds__(BS, (ISECT == 5 || ISECT == 6) ? RT_MINWAVES_LTREE 
                 if (slot_done) {
                     const uint32_t rk = __builtin_amdgcn_mbcnt_lo(complete, 0u);
                     wq.stack[sp + rk] = (uint8_t)lane;
-                    wq.cnt[lane] = SLOT_FREE;
+                    wq.cnt[cold<QNODES>(lane)] = SLOT_FREE;
                 }
                 sp = uni(sp + n_complete);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1975,9 +1985,9 @@ __global__ __launch_bounds__(BS, (ISECT == 5 || ISECT == 6) ? RT_MINWAVES_LTREE 
                     const V3 n = nn;
                     // push the hit on the path stack: albedo product is applied back-to-front
                     if (p.path32)
-                        reinterpret_cast<uint32_t*>(lpath)[k * BLOCK + tid] = (uint32_t)h.idx;
+                        reinterpret_cast<uint32_t*>(lpath)[k * BLOCK + cold<QNODES>(tid)] = (uint32_t)h.idx;
                     else
-                        reinterpret_cast<uint16_t*>(lpath)[k * BLOCK + tid16] = (uint16_t)h.idx;
+                        reinterpret_cast<uint16_t*>(lpath)[k * BLOCK + cold<QNODES>(tid16)] = (uint16_t)h.idx;
                     k++;
                     depth_left--;
                     if (depth_left == 0) {
@@ -2020,8 +2030,8 @@ __global__ __launch_bounds__(BS, (ISECT == 5 || ISECT == 6) ? RT_MINWAVES_LTREE 
                 // pair costs one trip to L2, not two; the products are taken in the same order (c5 +0.4 %, round 3)
                 {
                     auto path_idx = [&](uint32_t i) -> uint32_t {
-                        return p.path32 ? reinterpret_cast<uint32_t*>(lpath)[i * BLOCK + tid]
-                                        : (uint32_t) reinterpret_cast<uint16_t*>(lpath)[i * BLOCK + tid16];
+                        return p.path32 ? reinterpret_cast<uint32_t*>(lpath)[i * BLOCK + cold<QNODES>(tid)]
+                                        : (uint32_t) reinterpret_cast<uint16_t*>(lpath)[i * BLOCK + cold<QNODES>(tid16)];
                     };
                     uint32_t i = k;
 #pragma clang loop unroll(disable)
