@@ -127,13 +127,12 @@ constexpr uint32_t STAGE_TILES = 3;               // output staging: tiles a wav
 struct WaveQ {
     uint32_t cnt[SLOTS_MAX];                     // per slot: bits 0-12 units not yet finished (0: complete, waiting for its commit), bits 13-30 the ray
                                                  //   segments its finished units traced (per-strip cost), bit 31 = SLOT_FREE
-    uint8_t stack[SLOTS_MAX];                    // the free slots, last freed on top (a slot that was just written is reused first: L2)
     // per-strip cost (KParams::strip_cost): ray segments of committed slots not yet added to the launch's array, for TWO strips — [0] the
     // one the wave issues from, [1] the one before it (slots of both are in flight when the wave crosses a strip boundary)
     uint32_t cost_acc[2];
     uint32_t cost_strip[2];
 };
-static_assert(sizeof(WaveQ) == 176, "WaveQ layout (rt_api.hip: LDS_LIMIT leaves 3 KiB of static LDS)");
+static_assert(sizeof(WaveQ) == 144, "WaveQ layout (rt_api.hip: LDS_LIMIT leaves 3 KiB of static LDS)");
 constexpr uint32_t COST_COPIES = 16;
 constexpr uint32_t SLOT_UNIT_BITS = 13;           // units of a slot < 2^13 (spp <= RT_MAX_SPP = 4096), segments of a slot < 2^18 (x 63 bounces)
 struct WaveStage {                               // kernels with output staging only
@@ -665,11 +664,8 @@ __global__ __launch_bounds__(BS, (ISECT == 5 || ISECT == 6) ? RT_MINWAVES_LTREE 
     __shared__ WaveStage wave_st[CAN_STAGE ? BS / 64 : 1];
     {
         uint32_t* z = reinterpret_cast<uint32_t*>(&wave_q[threadIdx.x >> 6]);
-        // every slot free: counters SLOT_FREE, the stack holds n_slots - 1 ... 0 (slot 0 on top)
-        if ((threadIdx.x & 63u) < SLOTS_MAX) {
-            wave_q[threadIdx.x >> 6].cnt[threadIdx.x & 63u] = SLOT_FREE;
-            wave_q[threadIdx.x >> 6].stack[threadIdx.x & 63u] = (uint8_t)(p.n_slots - 1u - min(threadIdx.x & 63u, p.n_slots - 1u));
-        }
+        // every slot free
+        if ((threadIdx.x & 63u) < SLOTS_MAX) wave_q[threadIdx.x >> 6].cnt[threadIdx.x & 63u] = SLOT_FREE;
         if ((threadIdx.x & 63u) == 0u) {
             wave_q[threadIdx.x >> 6].cost_acc[0] = wave_q[threadIdx.x >> 6].cost_acc[1] = 0u;
             wave_q[threadIdx.x >> 6].cost_strip[0] = wave_q[threadIdx.x >> 6].cost_strip[1] = 0xffffffffu;
@@ -757,7 +753,9 @@ __global__ __launch_bounds__(BS, (ISECT == 5 || ISECT == 6) ? RT_MINWAVES_LTREE 
 #define wq wave_q[wave]
 #define wst wave_st[CAN_STAGE ? wave : 0u]
     float* const ring = p.ring + (size_t)(blockIdx.x * (uint32_t)(BLOCK / 64) + wave) * ((size_t)p.n_slots * p.slot_stride * 3u);
-    uint32_t sp = p.n_slots;                  // free slots (height of wq.stack)
+    const uint32_t all_free = p.n_slots >= 32u ? 0xffffffffu : (1u << p.n_slots) - 1u;
+    uint32_t freem = all_free;                // the free pixel slots.  The LOWEST free slot is taken first: the slots in use — and with them the
+                                              // part of the scratch that L2 has to hold — are the low ones unless a burst of long paths needs more
     uint32_t cur_slot = 0;                    // the open slot: the one the tile's next unit belongs to (unless that unit starts a slot)
     uint32_t tile_u = 0, tile_units = 0;      // issue tile: its next unit, its units (npix * spp); pixel-major: unit = pixel-in-tile * spp + sample
     uint32_t tile_x0 = 0, tile_row = 0, tile_yg = 0;   // ... decoded once: first column, row within the strip, GLOBAL row (main.rs:66-68)
@@ -849,7 +847,7 @@ __global__ __launch_bounds__(BS, (ISECT == 5 || ISECT == 6) ? RT_MINWAVES_LTREE 
         // (the cursors are wave-uniform by construction; every assignment says so — uni() — so that they live in scalar registers
         // across the loop: left to the compiler they travelled through vector registers, a dozen moves per round)
         // ================= commit: complete slots -> pixels (main.rs:73-81)
-        if (sp != p.n_slots) {
+        if (freem != all_free) {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");          // the lanes' deposits of the last round
             const bool slot_done = (uint32_t)lane < SLOTS_MAX && (wq.cnt[cold<QNODES>(lane) & (int)(SLOTS_MAX - 1u)] & (SLOT_FREE | ((1u << SLOT_UNIT_BITS) - 1u))) == 0u;
             const uint32_t complete = (uint32_t)__ballot(slot_done);         // (an open slot's counter still holds its unissued units)
@@ -857,7 +855,7 @@ __global__ __launch_bounds__(BS, (ISECT == 5 || ISECT == 6) ? RT_MINWAVES_LTREE 
             // Worth the instructions?  A commit runs at one lane per pixel, so it waits until commit_slots are complete — unless
             // the wave is about to run out of slots (lanes would go without units) or nothing is left to issue.
             const bool issue_over = q_drained && tile_u == tile_units;
-            if (n_complete >= p.commit_slots || (n_complete != 0u && (sp < 2u || issue_over))) {
+            if (n_complete >= p.commit_slots || (n_complete != 0u && ((uint32_t)__builtin_popcount(freem) < 2u || issue_over))) {
                 WCOUNT(14);
                 // the colours were stored by other lanes of this wave in earlier rounds: every store has reached L2 before the loads
                 // are issued, and the loads are of agent scope (they do not take a stale line of the CU's vector L1)
@@ -977,13 +975,9 @@ __global__ __launch_bounds__(BS, (ISECT == 5 || ISECT == 6) ? RT_MINWAVES_LTREE 
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // reads done before a slot is written again
                     }
                 }
-                // the committed slots are free again: on the stack, in any order
-                if (slot_done) {
-                    const uint32_t rk = __builtin_amdgcn_mbcnt_lo(complete, 0u);
-                    wq.stack[sp + rk] = (uint8_t)lane;
-                    wq.cnt[cold<QNODES>(lane)] = SLOT_FREE;
-                }
-                sp = uni(sp + n_complete);
+                // the committed slots are free again
+                if (slot_done) wq.cnt[cold<QNODES>(lane)] = SLOT_FREE;
+                freem = uni(freem | complete);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             }
         }
@@ -1098,7 +1092,7 @@ __global__ __launch_bounds__(BS, (ISECT == 5 || ISECT == 6) ? RT_MINWAVES_LTREE 
                 }
                 // ---- The tile's next units, all needy lanes at once: the lane of rank r takes unit tv = tile_u + r.  The tile's units
                 // are cut into slots of U = grp * spp (the last one may be short): unit tv belongs to the tile's slot number tv / U.
-                // Slots up to the one tile_u - 1 lies in are open already (that one is cur_slot); the others come off the free stack,
+                // Slots up to the one tile_u - 1 lies in are open already (that one is cur_slot); the others are the lowest free slots in turn,
                 // and the lane that takes a slot's first unit sets the slot up (counter, header).
                 bool got = false;
                 uint32_t tv = 0;
@@ -1108,17 +1102,19 @@ __global__ __launch_bounds__(BS, (ISECT == 5 || ISECT == 6) ? RT_MINWAVES_LTREE 
                     const uint32_t want = (uint32_t)__builtin_popcountll(mask);
                     const uint32_t U = p.slot_stride - 1u;
                     const uint32_t k_open = __umulhi(tile_u + U - 1u, p.slotu_magic);    // slots of this tile opened so far = ceil(tile_u / U)
-                    const uint32_t slot_room = (k_open + sp) * U - tile_u;                // units until the free slots run out
+                    const uint32_t n_free = (uint32_t)__builtin_popcount(freem);
+                    const uint32_t slot_room = (k_open + n_free) * U - tile_u;            // units until the free slots run out
                     const uint32_t take = min(want, min(tile_units - tile_u, slot_room));
                     stall = take < want && take == slot_room;                             // out of slots: wait for commits
+                    const uint32_t n_new = __umulhi(tile_u + take + U - 1u, p.slotu_magic) - k_open;   // slots this step opens (wave-uniform)
                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
                     got = need && rank < take;
                     tv = tile_u + rank;
                     const uint32_t k = __umulhi(tv, p.slotu_magic);                       // tv / U
                     const uint32_t unit = tv - __umul24(k, U);
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    const uint32_t fresh = (uint32_t)wq.stack[(sp - 1u - (k - k_open)) & (SLOTS_MAX - 1u)];   // (meaningful where k >= k_open)
-                    const uint32_t slot = k >= k_open ? fresh : cur_slot;
+                    uint32_t m = freem;                                                   // the (k - k_open)-th lowest free slot (where k >= k_open)
+                    for (uint32_t i = 0; i + 1u < n_new; i++) m = k > k_open + i ? (m & (m - 1u)) : m;
+                    const uint32_t slot = k >= k_open ? (uint32_t)__builtin_ctz(m | 0x80000000u) : cur_slot;
                     if (got) {
                         useq = (slot << 24) | unit;
                         if (unit == 0u) {
@@ -1132,10 +1128,11 @@ __global__ __launch_bounds__(BS, (ISECT == 5 || ISECT == 6) ? RT_MINWAVES_LTREE 
                     }
                     // the cursors, wave-uniformly
                     tile_u = uni(tile_u + take);
-                    const uint32_t n_new = __umulhi(tile_u + U - 1u, p.slotu_magic) - k_open;
                     if (n_new) {
-                        sp = uni(sp - n_new);
-                        cur_slot = uni((uint32_t)wq.stack[sp & (SLOTS_MAX - 1u)]);
+                        uint32_t fm = freem;
+                        for (uint32_t i = 0; i + 1u < n_new; i++) fm &= fm - 1u;
+                        cur_slot = uni((uint32_t)__builtin_ctz(fm));
+                        freem = uni(fm & (fm - 1u));
                     }
                 }
                 TSTAMP(7);
@@ -1207,7 +1204,7 @@ __global__ __launch_bounds__(BS, (ISECT == 5 || ISECT == 6) ? RT_MINWAVES_LTREE 
         }
         TSTAMP(1);
         // the wave is done when nothing is left to issue and everything issued is committed (wave-uniform: the lanes leave together)
-        const bool wave_busy = __ballot(active) != 0ull || sp != p.n_slots || !q_drained || tile_u != tile_units;
+        const bool wave_busy = __ballot(active) != 0ull || freem != all_free || !q_drained || tile_u != tile_units;
         if (STREAMED) {
             if (!__syncthreads_or(wave_busy ? 1 : 0)) break;
         } else {

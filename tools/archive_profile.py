@@ -91,6 +91,16 @@ if insts and busy:
                             "about twice that for min / max / cmp / cndmask / shifts / cvt / integer multiply.  lane_weighted_frac "
                             "= issue x active lanes / 64.",
                     "profile": f"profiles/{rnd}_{tag}_rocprof_summary.txt"}
+    # round 4: the profiler's own derived busy / utilisation metrics (their own --pmc passes, tools/prof4.sh), where collected
+    derived = {k: per_dispatch(k) for k in ("VALUBusy", "VALUUtilization", "SALUBusy", "LDSBankConflict", "MemUnitStalled")}
+    if any(v is not None for v in derived.values()):
+        di[workload]["derived_metrics_percent"] = derived
+        di[workload]["derived_metrics_note"] = (
+            "rocprofv3 derived metrics (gfx94x formulas: ROCm 7.2 ships no gfx950 section).  VALUBusy = 100 x SQ_ACTIVE_INST_VALU "
+            "[quad-cycles a wave spends on VALU instructions, summed over waves] / CUs / cycles, i.e. per SIMD the sum of its waves' "
+            "VALU windows over the elapsed time: it exceeds 100 when the windows of the four waves of a SIMD overlap — there is no "
+            "idle vector-pipe time to find.  VALUUtilization = active lanes / 64 of the VALU instructions.  SALUBusy likewise for "
+            "scalar instructions; LDSBankConflict = conflict cycles / elapsed cycles per CU; MemUnitStalled = TA data stall share.")
     json.dump(di, open(pi, "w"), indent=1)
     print(json.dumps(di[workload], indent=1))
 print(json.dumps(d.get(workload), indent=1))
