@@ -495,13 +495,13 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
         p.grp_magic = p.grp > 1u ? (uint32_t)((1ull << 32) / p.grp) + 1u : 0u;
         p.slot_stride = 1u + (uint32_t)slot_units;
         // enough slots for the pixels in flight (64 lanes' units, each pixel open as long as its longest path) plus the complete
-        // ones a commit waits for — and no more: the slots in use are scratch that L2 has to keep between a sample's store and its
-        // pixel's commit, and what L2 does not keep goes out to HBM and comes back (c3, WRITE_SIZE per 23.7 MiB frame: 32 slots 135 ...
-        // 260 MiB, 24 slots 88, 20 slots 40; Mrays/s 15 580 / 15 330 / 15 270).  192 units per wave = 24 slots at 8 spp; fewer at large
-        // sample counts, where a slot is kilobytes
+        // ones a commit waits for.  The price of every slot is scratch that L2 has to keep between a sample's store and its pixel's
+        // commit; what L2 does not keep goes out to HBM (c3, WRITE_SIZE per 23.7 MiB frame / Mrays/s: 32 slots 135 / 15 580, 24 slots
+        // 88 / 15 330, 20 slots 40 / 15 270, 16 slots 33 / 14 300; c4 at 12 / 16 / 24 slots: 15 615 / 16 070 / 16 220 Mrays/s).  The
+        // rate is what this path is measured by, HBM is idle either way (c3: 20 GB/s of 8 TB/s): 384 units per wave, at most 32 slots
         const int forced = dbg(DBG_SLOTS);
         p.n_slots = forced > 0 ? std::min<uint32_t>((uint32_t)forced, rtk::SLOTS_MAX)
-                               : (uint32_t)std::min<uint64_t>(rtk::SLOTS_MAX, std::max<uint64_t>(4u, 192u / slot_units));
+                               : (uint32_t)std::min<uint64_t>(rtk::SLOTS_MAX, std::max<uint64_t>(4u, 384u / slot_units));
         const uint32_t cs = dbg(DBG_COMMIT_SLOTS) > 0 ? (uint32_t)dbg(DBG_COMMIT_SLOTS) : std::max<uint32_t>(1u, p.n_slots / 4u);     // (c3: 4 ... 20 of 32 within 1 %)
         p.commit_slots = std::min<uint32_t>(cs, p.n_slots);
         // q / d == mulhi(q, floor(2^32 / d) + 1) whenever q * d < 2^32: q < 65 * spp with spp <= RT_MAX_SPP (4096)
