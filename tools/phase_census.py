@@ -17,9 +17,9 @@ sph, tri, rq = scenes.config_world(sys.argv[1] if len(sys.argv) > 1 else "c3")
 reqs = []
 for k in range(rq.divisions):
     r = rq.copy(); r.division_no = k; r.flags = int(sys.argv[2]) if len(sys.argv) > 2 else 0; reqs.append(r)
-names = ["main-loop iterations", "pixel acquisition body", "camera gen", "UnitDisc loop iters", "broad pass-branch entries",
+names = ["main-loop iterations", "unit acquisition body", "camera gen", "UnitDisc loop iters", "broad pass-branch entries",
          "narrow loop iters", "exact hits -> consider", "bvh validation", "shade hit branch", "scatter (UnitSphere)",
-         "UnitSphere loop iters", "sky branch", "finish", "path product loop iters", "pixel finalize"]
+         "UnitSphere loop iters", "sky branch", "finish", "path product loop iters", "slot commit (per pixel)"]
 with rt.Scene(0, rt.World(sph, tri)) as sc:
     outs, _, st = sc.render_tiles(reqs)
     lib = _abi.load()
@@ -35,9 +35,9 @@ with rt.Scene(0, rt.World(sph, tri)) as sc:
         print(f"  [{i:2d}] {n:28s} {buf[i]:12d}   per iteration {buf[i] / it:7.3f}")
     lbuf = (C.c_ulonglong * 64)()
     lib.rt_debug_read_counters(sc._h, 4 + 8192 + 32, 64, lbuf)
-    lnames = ["pixel acquisition", "sampler loop round", "ray generation (common)", "  bounce part", "  camera part",
+    lnames = ["unit acquisition", "sampler loop round", "ray generation (common)", "  bounce part", "  camera part",
               "traversal step", "root-test (flush) round", "shade classify", "  hit branch", "  sky branch", "finish path",
-              "  path product round", "pixel finalize"]
+              "  path product round", "slot commit (per pixel)"]
     print("active lanes per execution (of 64):")
     for i, n in enumerate(lnames):
         if lbuf[32 + i]:
