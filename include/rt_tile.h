@@ -178,7 +178,8 @@ typedef struct rt_tile_stats {
                                    3 BVH traversal (quantised nodes + exact leaf validation),
                                    4 BVH traversal, exact nodes resident in LDS,
                                    5 BVH traversal, quantised nodes, nearer child first with distance culling,
-                                   6 BVH traversal, exact nodes, nearer child first with distance culling (scenes with triangles) */
+                                   6 BVH traversal, exact nodes, nearer child first with distance culling (scenes with triangles),
+                                   7 BVH traversal, exact nodes resident in LDS, nearer child first with distance culling */
     uint32_t broad_form;        /* linear engines: 0 = oc form, 1 = expanded form   */
     uint64_t node_steps;        /* traversal engines under RT_FLAG_COUNT_STEPS: internal BVH nodes visited
                                    (each = two child-box slab tests); 0 otherwise.  broad_candidates = leaves
