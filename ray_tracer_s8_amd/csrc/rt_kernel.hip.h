@@ -555,15 +555,22 @@ __device__ __forceinline__ uint8_t f32_as_u8(float v) {
 // consecutive stamps are charged to the phase named by the stamp that ends the interval; one total per phase in
 // the spare queue slots [8192 + 160 ..].
 #ifdef RT_PROFILE_TIME
-#define TDECL unsigned long long _tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long _tlast = __builtin_amdgcn_s_memtime(); const unsigned long long _t0 = __builtin_amdgcn_s_memrealtime()
+#define TDECL unsigned long long _tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long _tlast = __builtin_amdgcn_s_memtime(); const unsigned long long _t0 = __builtin_amdgcn_s_memrealtime(); unsigned long long _tq = 0, _nq = 0
+#define TDRAINED do { _tq = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define TROUND do { _nq += _tq ? 1ull : 0ull; } while (0)
 #define TSTAMP(ph) do { const unsigned long long _n = __builtin_amdgcn_s_memtime(); _tacc[ph] += _n - _tlast; _tlast = _n; } while (0)
 // (+ per launch: [168] latest wave end, [169] sum of the waves' ends, [170] earliest wave start, [171] waves, [172] sum of the waves'
-//  starts — s_memrealtime: the 100 MHz counter all XCDs share (s_memtime runs per XCD): the tail is waves x [168] - [169])
+//  starts — s_memrealtime: the 100 MHz counter all XCDs share (s_memtime runs per XCD): the tail is waves x [168] - [169];
+//  [256 + w], last launch: wave w's end (28 bits), the time it found the queue empty (28 bits), its loop rounds from there on (8 bits))
 #define TFLUSH do { if ((threadIdx.x & 63) == 0) { for (int _i = 0; _i < 8; _i++) atomicAdd(&p.counters[4 + 8192 + 160 + _i], _tacc[_i]); \
     const unsigned long long _te = __builtin_amdgcn_s_memrealtime(); atomicMax(&p.counters[4 + 8192 + 168], _te); atomicAdd(&p.counters[4 + 8192 + 169], _te); \
-    atomicMin(&p.counters[4 + 8192 + 170], _t0); atomicAdd(&p.counters[4 + 8192 + 171], 1ull); atomicAdd(&p.counters[4 + 8192 + 172], _t0); } } while (0)
+    atomicMin(&p.counters[4 + 8192 + 170], _t0); atomicAdd(&p.counters[4 + 8192 + 171], 1ull); atomicAdd(&p.counters[4 + 8192 + 172], _t0); \
+    const uint32_t _w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); \
+    if (_w < 7900u) p.counters[4 + 8192 + 256 + _w] = (_te & 0xfffffffull) | ((_tq & 0xfffffffull) << 28) | (min(_nq, 255ull) << 56); } } while (0)
 #else
 #define TDECL do { } while (0)
+#define TDRAINED do { } while (0)
+#define TROUND do { } while (0)
 #define TSTAMP(ph) do { } while (0)
 #define TFLUSH do { } while (0)
 #endif
@@ -843,6 +850,7 @@ __global__ __launch_bounds__(BS, (ISECT == 5 || ISECT == 6) ? RT_MINWAVES_LTREE 
     for (;;) {
         WCOUNT(0);
         TSTAMP(5);
+        TROUND;
         uint32_t px = 0, pyg = 0;                 // a new unit's pixel: column, GLOBAL row — from the acquisition to the camera ray of this round
         // (the cursors are wave-uniform by construction; every assignment says so — uni() — so that they live in scalar registers
         // across the loop: left to the compiler they travelled through vector registers, a dozen moves per round)
@@ -1032,6 +1040,7 @@ __global__ __launch_bounds__(BS, (ISECT == 5 || ISECT == 6) ? RT_MINWAVES_LTREE 
                     t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
                     if (t == 0xffffffffu) {                   // queue drained: the wave ends when its units are committed
                         q_drained = true;
+                        TDRAINED;
                         break;
                     }
                     // queue entry -> tile (and quarter of it): whole tiles first, the last ones in quarters

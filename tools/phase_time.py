@@ -57,3 +57,19 @@ with rt.Scene(0, rt.World(sph, tri)) as sc:
         span = t_last - mean_start
         print(f"  {n_w} waves (s_memrealtime, 10 ns ticks): mean start -> latest end {span / 100:.1f} us; the mean wave ends "
               f"{(t_last - mean_end) / 100:.1f} us before the last one = {100.0 * (t_last - mean_end) / span:.1f} % of the span idle at the end")
+        # the distribution of the waves' ends (last launch): how far before the last wave the p-th percentile wave ended, when the waves
+        # found the queue empty, and how long they took from there to their end (the drain)
+        ends = (C.c_ulonglong * min(n_w, 7900))()
+        lib.rt_debug_read_counters(sc._h, 4 + 8192 + 256, len(ends), ends)
+        M = 0xfffffff
+        tl = t_last & M
+        vals = [int(v) for v in ends if int(v)]
+        e = sorted((tl - (v & M)) & M for v in vals)
+        dq = sorted((tl - ((v >> 28) & M)) & M for v in vals if (v >> 28) & M)
+        dr = sorted(((v & M) - ((v >> 28) & M)) & M for v in vals if (v >> 28) & M)
+        nr = sorted((v >> 56) * 100 for v in vals if (v >> 28) & M)
+        fr = (0.01, 0.1, 0.25, 0.5, 0.75, 0.9, 0.99)
+        for name, a in (("wave ends before the last end (us)", e[::-1]), ("queue found empty before the last end (us)", dq[::-1]),
+                        ("from queue-empty to the wave's end (us)", dr), ("loop rounds from queue-empty to the wave's end", nr)):
+            if a:
+                print(f"  {name}: " + "  ".join(f"p{int(f * 100)} {a[min(len(a) - 1, int(f * len(a)))] / 100:.0f}" for f in fr) + f"  max {a[-1] / 100:.0f}")
