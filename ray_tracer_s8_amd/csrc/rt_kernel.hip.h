@@ -605,6 +605,21 @@ __device__ __forceinline__ int cold(int v) {
     if (ON) asm volatile("" : "+v"(v));
     return v;
 }
+// A word of the wave's sample scratch, written by another lane of THIS wave in an earlier round (its store has completed: vmcnt(0)).
+// Wavefronts of one workgroup share the CU's vector L1, which is write-through: no cache action is needed between them (the compiler's
+// memory model for this chip says so in as many words), so these are plain loads the compiler may merge into dwordx3 / dwordx4 —
+// RT_COMMIT_AGENT_LOADS=1 restores the agent-scope loads of the first version (every word its own trip past the L1).
+#ifndef RT_COMMIT_AGENT_LOADS
+#define RT_COMMIT_AGENT_LOADS 0
+#endif
+template <class T>
+__device__ __forceinline__ T ring_load(const T* q) {
+#if RT_COMMIT_AGENT_LOADS
+    return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    return *q;
+#endif
+}
 // a wave-uniform value read through a vector register (LDS): back into a scalar register
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
@@ -865,8 +880,8 @@ __global__ __launch_bounds__(BS, (ISECT == 5 || ISECT == 6) ? RT_MINWAVES_LTREE 
             const bool issue_over = q_drained && tile_u == tile_units;
             if (n_complete >= p.commit_slots || (n_complete != 0u && ((uint32_t)__builtin_popcount(freem) < 2u || issue_over))) {
                 WCOUNT(14);
-                // the colours were stored by other lanes of this wave in earlier rounds: every store has reached L2 before the loads
-                // are issued, and the loads are of agent scope (they do not take a stale line of the CU's vector L1)
+                // the colours were stored by other lanes of this wave in earlier rounds: every store has completed before the loads
+                // are issued (ring_load: same CU, same write-through L1)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 const uint32_t n_lanes = p.n_slots * p.grp;               // lane L <-> pixel L % grp of slot L / grp
                 for (uint32_t l0 = 0; l0 < n_lanes; l0 += 64u) {
@@ -881,9 +896,9 @@ __global__ __launch_bounds__(BS, (ISECT == 5 || ISECT == 6) ? RT_MINWAVES_LTREE 
                         const float* sb = ring + __umul24(slot, p.slot_stride) * 3u;
                         // (header and the first samples are asked for together: one trip to L2, not two; a lane beyond the slot's
                         // pixels — the short last slot of a tile — sums records nobody wrote and stores nothing)
-                        const uint32_t hx = __hip_atomic_load(reinterpret_cast<const uint32_t*>(sb) + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        const uint32_t hrow = __hip_atomic_load(reinterpret_cast<const uint32_t*>(sb) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        const uint32_t hmeta = __hip_atomic_load(reinterpret_cast<const uint32_t*>(sb) + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const uint32_t hx = ring_load(reinterpret_cast<const uint32_t*>(sb) + 0);
+                        const uint32_t hrow = ring_load(reinterpret_cast<const uint32_t*>(sb) + 1);
+                        const uint32_t hmeta = ring_load(reinterpret_cast<const uint32_t*>(sb) + 2);
                         const float* r = sb + 3u + g * p.spp * 3u;
                         float sum_r = 0.f, sum_g = 0.f, sum_b = 0.f;
                         cstrip = hmeta & 0xffu;
@@ -896,7 +911,7 @@ __global__ __launch_bounds__(BS, (ISECT == 5 || ISECT == 6) ? RT_MINWAVES_LTREE 
                                 LCOUNT(12);
                                 float c[3 * CB];
 #pragma unroll
-                                for (int e = 0; e < 3 * CB; e++) c[e] = __hip_atomic_load(r + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                for (int e = 0; e < 3 * CB; e++) c[e] = ring_load(r + e);
 #pragma unroll
                                 for (int e = 0; e < CB; e++) {
                                     sum_r = sum_r + c[3 * e + 0];
@@ -908,9 +923,9 @@ __global__ __launch_bounds__(BS, (ISECT == 5 || ISECT == 6) ? RT_MINWAVES_LTREE 
 #pragma clang loop unroll(disable)
                             for (; i < p.spp; i++) {
                                 LCOUNT(12);
-                                const float cr = __hip_atomic_load(r + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                const float cg = __hip_atomic_load(r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                const float cb = __hip_atomic_load(r + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                const float cr = ring_load(r + 0);
+                                const float cg = ring_load(r + 1);
+                                const float cb = ring_load(r + 2);
                                 sum_r = sum_r + cr;
                                 sum_g = sum_g + cg;
                                 sum_b = sum_b + cb;
