@@ -261,7 +261,11 @@ int get_events(rt_scene* sc, EvPair& ev) {
 }
 
 constexpr uint32_t QUEUE_SLOTS = 16384;          // uncollected launches per scene (one 8-byte queue head each)
+#ifdef RT_PROFILE_TIME
+constexpr uint32_t COUNTER_WORDS = 4 + QUEUE_SLOTS + 16 * 8192;      // (+ one block per wave: the phase clock, tools/phase_time.py)
+#else
 constexpr uint32_t COUNTER_WORDS = 4 + QUEUE_SLOTS;
+#endif
 
 bool same_frame(const rt_tile_request& a, const rt_tile_request& b) {
     return a.width == b.width && a.height == b.height && a.divisions == b.divisions && a.spp == b.spp &&

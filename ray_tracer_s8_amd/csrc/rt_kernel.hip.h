@@ -553,20 +553,22 @@ __device__ __forceinline__ uint8_t f32_as_u8(float v) {
 #endif
 // Phase clock for tuning (compile with -DRT_PROFILE_TIME; tools/phase_time.py): wave cycles (s_memtime) between
 // consecutive stamps are charged to the phase named by the stamp that ends the interval; one total per phase in
-// the spare queue slots [8192 + 160 ..].
+// a block of the wave's own (TFLUSH).
 #ifdef RT_PROFILE_TIME
 #define TDECL unsigned long long _tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long _tlast = __builtin_amdgcn_s_memtime(); const unsigned long long _t0 = __builtin_amdgcn_s_memrealtime(); unsigned long long _tq = 0, _nq = 0
 #define TDRAINED do { _tq = __builtin_amdgcn_s_memrealtime(); } while (0)
-#define TROUND do { _nq += _tq ? 1ull : 0ull; } while (0)
+// (+ for every 20th wave, the start of each of its first 16 rounds after the queue ran dry and the lanes that still hold a unit: [4400 + (w / 20) * 16 + round])
+#define TROUND do { if (_tq) { const uint32_t _w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); const unsigned long long _lv = __builtin_popcountll(__ballot(have_unit)); \
+    if ((threadIdx.x & 63) == 0 && _w % 20u == 0u && _w / 20u < 215u && _nq < 16ull) p.counters[4 + 8192 + 4400 + (_w / 20u) * 16u + _nq] = (__builtin_amdgcn_s_memrealtime() & 0xfffffffull) | (_lv << 28); \
+    _nq++; } } while (0)
 #define TSTAMP(ph) do { const unsigned long long _n = __builtin_amdgcn_s_memtime(); _tacc[ph] += _n - _tlast; _tlast = _n; } while (0)
-// (+ per launch: [168] latest wave end, [169] sum of the waves' ends, [170] earliest wave start, [171] waves, [172] sum of the waves'
-//  starts — s_memrealtime: the 100 MHz counter all XCDs share (s_memtime runs per XCD): the tail is waves x [168] - [169];
-//  [256 + w], last launch: wave w's end (28 bits), the time it found the queue empty (28 bits), its loop rounds from there on (8 bits))
-#define TFLUSH do { if ((threadIdx.x & 63) == 0) { for (int _i = 0; _i < 8; _i++) atomicAdd(&p.counters[4 + 8192 + 160 + _i], _tacc[_i]); \
-    const unsigned long long _te = __builtin_amdgcn_s_memrealtime(); atomicMax(&p.counters[4 + 8192 + 168], _te); atomicAdd(&p.counters[4 + 8192 + 169], _te); \
-    atomicMin(&p.counters[4 + 8192 + 170], _t0); atomicAdd(&p.counters[4 + 8192 + 171], 1ull); atomicAdd(&p.counters[4 + 8192 + 172], _t0); \
-    const uint32_t _w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); \
-    if (_w < 7900u) p.counters[4 + 8192 + 256 + _w] = (_te & 0xfffffffull) | ((_tq & 0xfffffffull) << 28) | (min(_nq, 255ull) << 56); } } while (0)
+// At its end every wave writes ONE block of 16 words of its own behind the queue slots — [4 + 16384 + 16 w ..]: the eight phase totals, its
+// end, start and queue-empty times (s_memrealtime: the 100 MHz counter all XCDs share; s_memtime runs per XCD) and its rounds after the
+// queue ran dry.  Plain stores: the first version added them to shared words, and 50 000 same-address atomics at the end of a launch held
+// up the very rounds they were timing (drain rounds of 100-200 us among 10 us ones).
+#define TFLUSH do { if ((threadIdx.x & 63) == 0) { const uint32_t _w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); \
+    if (_w < 8192u) { unsigned long long* _b = p.counters + 4 + 16384 + 16u * _w; for (int _i = 0; _i < 8; _i++) _b[_i] = _tacc[_i]; \
+    _b[8] = __builtin_amdgcn_s_memrealtime(); _b[9] = _t0; _b[10] = _tq; _b[11] = _nq; } } } while (0)
 #else
 #define TDECL do { } while (0)
 #define TDRAINED do { } while (0)
