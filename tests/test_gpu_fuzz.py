@@ -60,6 +60,12 @@ def _random_case(i):
                               fov=float(g.choice([0.6, 1.5707964, 2.2])), focal_length=float(g.choice([1.0, 2.0])),
                               t_min=float(g.choice([0.001, 0.05])), t_max=float(g.choice([1000.0, 12.0 * scale])),
                               seed=int(g.integers(0, 2**63)))
+    if i % 5 == 3:
+        # round 4 (sample units): every fifth case at 8 samples per pixel and more — one pixel per slot, counts that are not powers
+        # of two, slots of up to 100 units; own generator: the other cases stay what they were
+        g2 = np.random.default_rng(88000 + i)
+        rq.spp = int(g2.choice([8, 9, 13, 16, 31, 64, 100]))
+        rq.width, rq.height = max(1, rq.width // 2), max(rq.divisions, rq.height // 2)
     flags = int(ENGINE_FLAGS[i % len(ENGINE_FLAGS)])
     return sph, tri, rq, flags
 
