@@ -166,9 +166,11 @@ struct KParams {
     uint32_t n_strips;           // strips in this launch
     uint32_t tiles_x, tiles_per_strip;            // tiles of 64x1 pixels (three whole 64-B lines of RGB8 per tile)
     uint32_t tiles_total;        // tiles of the launch (tiles_per_strip * n_strips)
-    uint32_t tiles_big;          // the first tiles_big entries of the launch's queue are whole tiles, every later one is a QUARTER (16 pixels)
+    uint32_t tiles_big;          // the first tiles_big entries of the launch's queue are whole tiles, every later one a PART of one: a quarter
+                                 // (16 pixels; sub_shift 2) or a sixteenth (4 pixels; sub_shift 4: many samples per pixel)
+    uint32_t sub_shift;
                                  //   of one of the remaining tiles: the launch ends on small pieces (its tail is one piece long)
-    uint32_t n_tiles;            // queue entries: tiles_big + 4 * (tiles_total - tiles_big)
+    uint32_t n_tiles;            // queue entries: tiles_big + ((tiles_total - tiles_big) << sub_shift)
     uint32_t n_slots;            // sample units: pixel slots per wave (<= SLOTS_MAX)
     uint32_t grp;                //   pixels per slot (1 from 8 spp up; 8 / spp below, so that a slot is at least 8 units)
     uint32_t grp_magic;          //   floor(2^32 / grp) + 1 (grp > 1)
@@ -1064,9 +1066,9 @@ __global__ __launch_bounds__(BS, (ISECT == 5 || ISECT == 6) ? RT_MINWAVES_LTREE 
                     uint32_t sub = 0u, tw = 64u;
                     if (t >= p.tiles_big) {
                         const uint32_t e = t - p.tiles_big;
-                        t = p.tiles_big + (e >> 2);
-                        sub = (e & 3u) << 4;
-                        tw = 16u;
+                        t = p.tiles_big + (e >> p.sub_shift);
+                        tw = 64u >> p.sub_shift;
+                        sub = (e & ((1u << p.sub_shift) - 1u)) * tw;
                     }
 #ifndef RT_TILES_TOP_DOWN
                     // Tiles are handed out from the END of the batch backwards: strips are listed top to bottom and the
