@@ -503,9 +503,14 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
         // commit; what L2 does not keep goes out to HBM (c3, WRITE_SIZE per 23.7 MiB frame / Mrays/s: 32 slots 135 / 15 580, 24 slots
         // 88 / 15 330, 20 slots 40 / 15 270, 16 slots 33 / 14 300; c4 at 12 / 16 / 24 slots: 15 615 / 16 070 / 16 220 Mrays/s).  The
         // rate is what this path is measured by, HBM is idle either way (c3: 20 GB/s of 8 TB/s): 384 units per wave, at most 32 slots
+        // — but never fewer than 16 pixels open while a pixel is at most 256 units: a slot is free again only when its LAST sample is in,
+        // and with the 4 slots the 384 units gave the reference's literal 100 samples per pixel a wave stood still for want of a slot
+        // (the mesh at 100 spp: 4 / 8 / 16 / 32 slots 6 990 / 7 250 / 7 340 / 7 370 Mrays/s); 8 up to 1 024 units, 4 beyond (scratch:
+        // 12 bytes per unit and slot for every wave of the grid)
         const int forced = dbg(DBG_SLOTS);
+        const uint64_t fewest = slot_units <= 256u ? 16u : slot_units <= 1024u ? 8u : 4u;
         p.n_slots = forced > 0 ? std::min<uint32_t>((uint32_t)forced, rtk::SLOTS_MAX)
-                               : (uint32_t)std::min<uint64_t>(rtk::SLOTS_MAX, std::max<uint64_t>(4u, 384u / slot_units));
+                               : (uint32_t)std::min<uint64_t>(rtk::SLOTS_MAX, std::max<uint64_t>(fewest, 384u / slot_units));
         const uint32_t cs = dbg(DBG_COMMIT_SLOTS) > 0 ? (uint32_t)dbg(DBG_COMMIT_SLOTS) : std::max<uint32_t>(1u, p.n_slots / 4u);     // (c3: 4 ... 20 of 32 within 1 %)
         p.commit_slots = std::min<uint32_t>(cs, p.n_slots);
         // q / d == mulhi(q, floor(2^32 / d) + 1) whenever q * d < 2^32: q < 65 * spp with spp <= RT_MAX_SPP (4096)
