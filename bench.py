@@ -60,7 +60,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "c5", "mesh", "mesh_ref"],
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "c5", "mesh", "mesh_ref", "c3_ref"],
                     help="BASELINE configs c2-c5, or `mesh`: a generated 100 352-triangle OBJ through the controller's ingest "
                          "rules at the controller's literal 1920x1080 / 20 strips (not a BASELINE config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -401,9 +401,9 @@ def main():
     if rank == 0 and world == 1 and not args.no_others and args.workload == "c3" and not args.flags and not args.overlap:
         others = {}
         # ("c3_again": the headline frame through this function, for its `value_3_streams` — the timed region above is single-stream)
-        for w in ("c2", "c4", "c5", "mesh", "mesh_ref", "c3_again"):
+        for w in ("c2", "c4", "c5", "mesh", "mesh_ref", "c3_ref", "c3_again"):
             try:
-                others[w] = other_workload(rt, scenes, w.split("_again")[0], dev_index, stream, torch, steps=2 if w == "mesh_ref" else 3)
+                others[w] = other_workload(rt, scenes, w.split("_again")[0], dev_index, stream, torch, steps=2 if w.endswith("_ref") else 3)
             except Exception as e:                   # a failure here must not take the headline line with it
                 others[w] = {"error": repr(e)}
     # ---- the in-process frame path (rt_frame_ctx: host frame out, dispatcher threads, pinned buffer), wall clock

@@ -613,6 +613,9 @@ __device__ __forceinline__ int cold(int v) {
 // Wavefronts of one workgroup share the CU's vector L1, which is write-through: no cache action is needed between them (the compiler's
 // memory model for this chip says so in as many words), so these are plain loads the compiler may merge into dwordx3 / dwordx4 —
 // RT_COMMIT_AGENT_LOADS=1 restores the agent-scope loads of the first version (every word its own trip past the L1).
+#ifndef RT_COMMIT_BATCH          // samples whose records a committing lane asks for in one trip
+#define RT_COMMIT_BATCH 8
+#endif
 #ifndef RT_COMMIT_AGENT_LOADS
 #define RT_COMMIT_AGENT_LOADS 0
 #endif
@@ -909,21 +912,27 @@ __global__ __launch_bounds__(BS, (ISECT == 5 || ISECT == 6) ? RT_MINWAVES_LTREE 
                         {
                             // pix_color += (main.rs:75), s = 0 .. spp - 1; the loads of four samples in flight together
                             uint32_t i = 0;
-                            constexpr int CB = 4;            // (eight per trip in the LDS-tree kernel, which has the registers: no difference)
+                            // (batches of RT_COMMIT_BATCH, then of four, then single samples: at the reference's 100 samples per pixel a
+                            // pixel's sum is 13 + 1 trips instead of 25)
+                            auto batch = [&](auto cb_tag) {
+                                constexpr int CB = decltype(cb_tag)::value;
 #pragma clang loop unroll(disable)
-                            for (; i + (uint32_t)CB <= p.spp; i += (uint32_t)CB) {
-                                LCOUNT(12);
-                                float c[3 * CB];
+                                for (; i + (uint32_t)CB <= p.spp; i += (uint32_t)CB) {
+                                    LCOUNT(12);
+                                    float c[3 * CB];
 #pragma unroll
-                                for (int e = 0; e < 3 * CB; e++) c[e] = ring_load(r + e);
+                                    for (int e = 0; e < 3 * CB; e++) c[e] = ring_load(r + e);
 #pragma unroll
-                                for (int e = 0; e < CB; e++) {
-                                    sum_r = sum_r + c[3 * e + 0];
-                                    sum_g = sum_g + c[3 * e + 1];
-                                    sum_b = sum_b + c[3 * e + 2];
+                                    for (int e = 0; e < CB; e++) {
+                                        sum_r = sum_r + c[3 * e + 0];
+                                        sum_g = sum_g + c[3 * e + 1];
+                                        sum_b = sum_b + c[3 * e + 2];
+                                    }
+                                    r += 3 * CB;
                                 }
-                                r += 3 * CB;
-                            }
+                            };
+                            if (RT_COMMIT_BATCH > 4 && !QNODES) batch(std::integral_constant<int, RT_COMMIT_BATCH>{});      // (the 96-register quantised kernels would spill)
+                            batch(std::integral_constant<int, 4>{});
 #pragma clang loop unroll(disable)
                             for (; i < p.spp; i++) {
                                 LCOUNT(12);

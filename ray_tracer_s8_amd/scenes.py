@@ -209,6 +209,9 @@ def config(name: str) -> tuple[np.ndarray, TileRequest]:
         # (1920x1080, 20 strips); spheres = none, triangles = mesh_world()
         return np.zeros(0, SPHERE_DTYPE), default_request(width=1920, height=1080, divisions=20, spp=4, max_bounces=4,
                                                           seed=0x0B1E5)
+    if name == "c3_ref":
+        # not a BASELINE config either: c3's 1024 spheres at the reference's literal settings (as mesh_ref below)
+        return rand1024(), default_request(seed=0x5EED0400)
     if name == "mesh_ref":
         # the same mesh at the reference's LITERAL settings: 1920x1080, 20 strips (controller main.rs:33-39), 100 samples per pixel,
         # 10 bounces (slave main.rs:39, 51) — what a job of the shipped controller + slave actually renders
