@@ -1185,10 +1185,11 @@ __global__ __launch_bounds__(BS, (ISECT == 5 || ISECT == 6) ? RT_MINWAVES_LTREE 
                     bounce = false;
                     need = false;
                 }
-                if (stall) break;
+                if (stall) { LCOUNT(14); break; }          // (census: rounds in which lanes go without a unit for want of a free slot)
             }
         }
         const bool active = have_unit;
+        if (!active) { LCOUNT(13); }                       // (census: lanes that idle through this round)
         TSTAMP(0);
         if (active && need_ray) {
             // ---- next ray of the lane: the camera ray of a new sample (Camera::get_ray, camera.rs:109-129) or the

@@ -37,7 +37,7 @@ with rt.Scene(0, rt.World(sph, tri)) as sc:
     lib.rt_debug_read_counters(sc._h, 4 + 8192 + 32, 64, lbuf)
     lnames = ["unit acquisition", "sampler loop round", "ray generation (common)", "  bounce part", "  camera part",
               "traversal step", "root-test (flush) round", "shade classify", "  hit branch", "  sky branch", "finish path",
-              "  path product round", "slot commit (per pixel)"]
+              "  path product round", "slot commit (per pixel)", "lanes idling through a round", "out of slots (lanes of the wave)"]
     print("active lanes per execution (of 64):")
     for i, n in enumerate(lnames):
         if lbuf[32 + i]:
