@@ -41,6 +41,7 @@ RT_FLAG_FRAME_QUEUE = 4096          # frame-level (rt_render_frame / rt_frame_ct
 RT_FLAG_FRAME_NO_PIN = 8192         # frame-level: do not page-lock the caller's frame buffer
 RT_FLAG_FRAME_STATIC = 16384        # frame-level: strip k -> devices[k % n] instead of the cost-balanced assignment
 RT_MAX_BOUNCES = 62
+RT_MAX_SPP = 4096                 # samples per pixel limit (rt_tile.h)
 
 # numpy dtypes with the exact layout of rt_sphere / rt_triangle (no padding)
 SPHERE_DTYPE = np.dtype(

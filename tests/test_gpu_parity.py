@@ -1036,6 +1036,24 @@ def test_tall_image_deep_paths_many_samples(ndev, oracle):
     _compare(oracle, rq3, scenes.cornell16())
 
 
+@pytest.mark.parametrize("spp,w,h", [(4096, 7, 3), (1000, 9, 5), (257, 70, 3), (33, 130, 7), (17, 67, 5)])
+def test_sample_counts_up_to_the_limit(ndev, oracle, spp, w, h):
+    """Round 4: the sample units at the counts the host rules change at — 17 (every tile in quarters), 33 (sixteenths), 257 (8 pixel
+    slots per wave instead of 16), 1 000, and RT_MAX_SPP = 4 096 (4 slots of 4 097 records) — on frames whose width is no multiple of
+    the part width, through the linear scan, the LDS-resident tree (plain and culled) and the L2-gather walks."""
+    assert spp <= _abi.RT_MAX_SPP
+    rq = _abi.default_request(width=w, height=h, divisions=1, spp=spp, max_bounces=6, seed=1234 + spp)
+    st = _compare(oracle, rq, scenes.cornell16())
+    assert st.engine == 0
+    sph, _ = scenes.config("c3")
+    if spp <= 1000:                                   # (the oracle's share of the run time: a 1 024-sphere scene at 4 096 spp is left out)
+        st = _compare(oracle, rq, sph)
+        assert st.engine in (4, 7)
+        _compare(oracle, rq, sph, flags=_abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_EXACT_NODES | _abi.RT_FLAG_CULL_WALK)
+        _compare(oracle, rq, sph, flags=_abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_EXACT_NODES | _abi.RT_FLAG_NO_LDS_TREE)
+        _compare(oracle, rq, sph, flags=_abi.RT_FLAG_BVH_TRAVERSE | _abi.RT_FLAG_QUANT_NODES | _abi.RT_FLAG_CULL_WALK)
+
+
 def test_subnormal_values(ndev, oracle):
     """binary32 subnormals in the scene (radii, coordinates, albedo, emission) and therefore in intermediate results: the kernels
     must not flush them (the reference's SSE arithmetic does not)."""
