@@ -135,8 +135,9 @@ constexpr float DENSE_SCAN_MIN_DENSITY = 3.0f;       // ... this keep the linear
 constexpr float LT_CULL_MIN_DENSITY = 2.2f;          // the LDS-resident tree is walked nearer child first, with distance culling, from this box density up
                                                      // (tests/test_gpu_engine_rules.py: at 1.1 ... 1.8 a helix, a lattice and a colonnade of 700 ... 960
                                                      // spheres lose 7 ... 17 % to the culled step, piles at 1.8 / 2.7 gain 2 / 38 %)
-constexpr float SMALL_TREE_MAX_DENSITY = 0.4f;      // sphere scenes of up to TRAVERSE_MIN_PRIMS spheres walk the tree below this box density (see `traverse`)
-constexpr uint32_t TRAVERSE_MIN_PRIMS = 32;     // above this many primitives the BVH-traversal engine is the default (measured with the LDS-resident tree: tools/crossover.py 0.91 at 16, 1.03 at 32, 1.10 at 64, 2.0 at 512; tools/heuristics_matrix.py at 48: +15...20 % on sparse fields, sheets and clusters, -3 % on dense overlap)
+constexpr uint32_t TRAVERSE_MIN_PRIMS = 2;      // from this many primitives up the BVH-traversal engine is the default.  (Rounds 1-3: 32, with a density rule below it;
+                                                // with the sample units the LDS-resident tree leads the scan on every scene of tools/small_scene_matrix.py —
+                                                // 2 ... 32 spheres, five families, 1.02 ... 1.36 x — but one pile of 32, and on c2's 16-sphere room by 5 ... 8 %.)
 
 }  // namespace
 
@@ -304,20 +305,15 @@ int launch_batch(rt_scene* sc, const rt_tile_request* rqs, uint32_t n, void* con
     const bool trav_ok = !(rq->flags & (RT_FLAG_EXACT_SCAN | RT_FLAG_NO_BVH_CULL | RT_FLAG_LINEAR_SCAN)) &&
                          sc->bvh_depth < (uint32_t)rtk::TRAV_STACK && n_prims > 0;   // LDS stack: (depth + 1) KiB per workgroup
     // (the linear engines test every triangle's box per segment: meshes switch to the tree much earlier)
-    // (... and so do SPARSE sphere scenes of any size from two spheres up: since round 3's work on the LDS-tree step the tree wins
-    // by 3...17 % wherever the culled walk's box density — the big spheres set aside — is below 0.4, and loses 1...15 % on piles of
-    // overlapping spheres at 1.1 and above; c2's room sits at 0.50 and stays with the scan it renders 2 % faster with.
-    // tools/small_scene_matrix.py: 33 scenes of 2...32 spheres)
-    const bool sparse_small = n_prims >= 2 && sc->n_tri == 0 && sc->cull_density < SMALL_TREE_MAX_DENSITY;
-    // (... while small PILES of overlapping spheres keep the scan: at a box density of 3 and more a ray meets so many leaf boxes that up
+    // (Small PILES of overlapping spheres keep the scan: at a box density of 3 and more a ray meets so many leaf boxes that up
     // to about 200 spheres the scan's 64 packed instructions per 8 spheres beat any walk — tools/dense_matrix.py, 48 ... 192 spheres at
     // density 3.3 ... 13: the culled LDS-tree walk of round 4 renders them at 0.67 ... 0.84 of the scan (the plain one: 0.59 ... 0.92), at
     // 256 it leads by 1.4 ... 1.5 x.  Round 3's two further pile rules — up to 384 spheres at densities 5 ... 12 to the scan, larger or
     // denser piles to the culled L2 walk although their tree fits LDS — are gone: the culled LDS-tree walk is the best engine in
     // every cell of tools/dense_mid_matrix.py, by 13 ... 30 %.)
     const bool dense_pile = sc->n_tri == 0 && n_prims <= DENSE_SCAN_MAX_PRIMS && sc->cull_density >= DENSE_SCAN_MIN_DENSITY;
-    const bool traverse = trav_ok && ((rq->flags & RT_FLAG_BVH_TRAVERSE) || (n_prims > TRAVERSE_MIN_PRIMS && !dense_pile) ||
-                                      sc->n_tri > TRAVERSE_MIN_TRIS || sparse_small);
+    const bool traverse = trav_ok && ((rq->flags & RT_FLAG_BVH_TRAVERSE) || (n_prims >= TRAVERSE_MIN_PRIMS && !dense_pile) ||
+                                      sc->n_tri > TRAVERSE_MIN_TRIS);
     // node format: from RT_QNODES_MIN_PRIMS primitives up the 32-byte quantised nodes (half the gather footprint, and an
     // LDS plan that keeps five workgroups per CU whatever the tree's depth): +14 % on sparse fields of every size, +17...29 %
     // on dense fields of 32 768+ spheres, within 2.5 % either way in between; below it the exact-node kernel's six

@@ -1043,7 +1043,7 @@ def test_sample_counts_up_to_the_limit(ndev, oracle, spp, w, h):
     the part width, through the linear scan, the LDS-resident tree (plain and culled) and the L2-gather walks."""
     assert spp <= _abi.RT_MAX_SPP
     rq = _abi.default_request(width=w, height=h, divisions=1, spp=spp, max_bounces=6, seed=1234 + spp)
-    st = _compare(oracle, rq, scenes.cornell16())
+    st = _compare(oracle, rq, scenes.cornell16(), flags=_abi.RT_FLAG_LINEAR_SCAN)
     assert st.engine == 0
     sph, _ = scenes.config("c3")
     if spp <= 1000:                                   # (the oracle's share of the run time: a 1 024-sphere scene at 4 096 spp is left out)
