@@ -50,7 +50,7 @@ F = _abi
 engines = [("linear", F.RT_FLAG_LINEAR_SCAN), ("L2 exact", F.RT_FLAG_BVH_TRAVERSE | F.RT_FLAG_EXACT_NODES | F.RT_FLAG_NO_LDS_TREE),
            ("L2 quant", F.RT_FLAG_BVH_TRAVERSE | F.RT_FLAG_QUANT_NODES), ("LDS tree", F.RT_FLAG_BVH_TRAVERSE | F.RT_FLAG_EXACT_NODES),
            ("default", 0)]
-names = {0: "linear", 1: "linear(streamed)", 2: "L2 exact", 3: "L2 quant", 4: "LDS tree", 5: "L2 quant culled", 6: "L2 exact culled"}
+names = {0: "linear", 1: "linear(streamed)", 2: "L2 exact", 3: "L2 quant", 4: "LDS tree", 5: "L2 quant culled", 6: "L2 exact culled", 7: "LDS tree culled"}
 print(f"{'scene':22s} " + " ".join(f"{e[0]:>10s}" for e in engines) + "   default picks / best")
 for name, sph, tri in cases:
     world = rt.World(sph if sph is not None else np.zeros(0, F.SPHERE_DTYPE), tri if tri is not None else np.zeros(0, F.TRIANGLE_DTYPE))
@@ -70,8 +70,8 @@ for name, sph, tri in cases:
             v = st.ray_segments / st.kernel_ms / 1e3
             if ename == "default":
                 picked = names[st.engine]
-            elif (ename != "LDS tree" or st.engine == 4) and v > best[0]:
+            elif (ename != "LDS tree" or st.engine in (4, 7)) and v > best[0]:
                 best = (v, names[st.engine])
-            row.append(f"{v:.0f}" + ("" if ename != "LDS tree" or st.engine == 4 else "*"))
+            row.append(f"{v:.0f}" + ("" if ename != "LDS tree" or st.engine in (4, 7) else "*"))
     print(f"{name:22s} " + " ".join(f"{c:>10s}" for c in row) + f"   {picked} / {best[1]}")
 print("(* = the tree does not fit LDS: the L2-gather engine ran)")
